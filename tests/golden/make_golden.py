@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by importing the reference's two importable
+hot-path modules.  Runs ONLY in the build container (needs /root/reference):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes (data only -- inputs and expected outputs, no reference source):
+  tests/golden/sigproc_golden.npz   PCM16 clips -> reference preemphasis /
+                                    framesig(rect) / powspec outputs
+  tests/golden/dscnn_golden.npz     seeded state_dicts + inputs -> reference
+                                    DepthwiseSeparableConv logits, per-layer probes
+
+Reference modules used (imported, never copied):
+  kws/libs/speech_features/sigproc.py:14-103   (framesig, magspec, powspec, preemphasis)
+  kws/libs/models.py:122-183                   (DepthwiseSeparableConv)
+The psf-only tail (mel/log/DCT/lifter/energy) has no importable reference
+here (python_speech_features absent) -> no golden vector for it: parity
+unpinned, covered by analytic known answers in tests/test_oracle.py.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from kws.libs import models as ref_models  # noqa: E402  (reference)
+from kws.libs.speech_features import sigproc as ref_sigproc  # noqa: E402  (reference)
+
+from oracle import dscnn as o_dscnn  # noqa: E402
+from oracle import psf_mfcc as o_mfcc  # noqa: E402
+
+N = 16000
+FRAME_LEN, FRAME_STEP, NFFT = 400, 160, 512
+KEEP_FRAMES = np.array([0, 1, 2, 48, 49, 50, 96, 97, 98])
+PROBE = [0, 4]  # samples whose activations are probed in detail (one random input, one MFCC input)
+
+
+def make_clips() -> "tuple[np.ndarray, list]":
+    rs = np.random.RandomState(20251004)
+    t = np.arange(N)
+    clips, names = [], []
+    names.append("zeros"); clips.append(np.zeros(N, np.int16))
+    imp = np.zeros(N, np.int16); imp[1000] = 32767
+    names.append("impulse@1000"); clips.append(imp)
+    names.append("square_fullscale_p64"); clips.append(np.where((t // 32) % 2 == 0, 32767, -32768).astype(np.int16))
+    names.append("sine_1kHz_a12000"); clips.append(np.round(12000 * np.sin(2 * np.pi * 1000 * t / 16000.0)).astype(np.int16))
+    names.append("uniform_fullrange"); clips.append(rs.randint(-32768, 32768, size=N).astype(np.int16))
+    names.append("gauss_sigma3000"); clips.append(np.clip(np.round(rs.standard_normal(N) * 3000), -32768, 32767).astype(np.int16))
+    quiet = np.zeros(N, np.int16); quiet[8000:] = rs.randint(-3, 4, size=N - 8000)
+    names.append("half_silent_lsb_noise"); clips.append(quiet)
+    names.append("dc_minus_full"); clips.append(np.full(N, -32768, np.int16))
+    return np.stack(clips), names
+
+
+def ones_window(n, device=None):
+    return torch.ones(n, dtype=torch.float64, device=device)
+
+
+def sigproc_golden():
+    clips, names = make_clips()
+    pre32, pspec, energy = [], [], []
+    for clip in clips:
+        x32 = torch.from_numpy(o_mfcc.pcm16_to_float(clip))           # float32, as librosa hands over
+        y32 = ref_sigproc.preemphasis(x32, 0.97)                      # reference, float32
+        frames = ref_sigproc.framesig(y32.double(), FRAME_LEN, FRAME_STEP, winfunc=ones_window)  # float64 like psf
+        ps = ref_sigproc.powspec(frames, NFFT).numpy()                # reference, float64 [99,257]
+        assert ps.shape == (99, 257) and ps.dtype == np.float64
+        # the oracle must agree with the reference before its output is trusted anywhere
+        o_y = o_mfcc.preemphasis(x32.numpy(), 0.97)
+        assert o_y.dtype == np.float32 and np.array_equal(o_y, y32.numpy())
+        o_ps = o_mfcc.powspec(o_mfcc.framesig(o_y, FRAME_LEN, FRAME_STEP), NFFT)
+        np.testing.assert_allclose(o_ps, ps, rtol=1e-9, atol=1e-18 + 1e-12 * ps.max())
+        pre32.append(y32.numpy()[:64].copy())
+        pspec.append(ps[KEEP_FRAMES])
+        energy.append(ps.sum(1))
+
+    # the recipe of the reference's own unit test (tests/kws/libs/speech_features/test_sigproc.py:8-21),
+    # with the rectangular window psf uses (the test as written feeds Hann on one side)
+    np.random.seed(0)
+    sig = np.random.rand(N)
+    fr = ref_sigproc.framesig(torch.tensor(sig), FRAME_LEN, FRAME_STEP, winfunc=ones_window)
+    mag = ref_sigproc.magspec(fr, NFFT).numpy()
+    o_mag = o_mfcc.magspec(o_mfcc.framesig(sig, FRAME_LEN, FRAME_STEP), NFFT)
+    np.testing.assert_allclose(o_mag, mag, rtol=1e-5, atol=1e-8)      # the reference test's own tolerance
+
+    np.savez_compressed(
+        os.path.join(HERE, "sigproc_golden.npz"),
+        clips=clips, names=np.array(names), keep_frames=KEEP_FRAMES,
+        preemph_head_f32=np.stack(pre32), powspec_f64=np.stack(pspec), frame_energy_f64=np.stack(energy),
+        reftest_magspec_f64=mag[KEEP_FRAMES], reftest_magspec_colsum_f64=mag.sum(0),
+    )
+    print("sigproc_golden.npz:", len(names), "clips", names)
+
+
+def probe_layers(layers: dict) -> dict:
+    """Compact, layout-sensitive summary of every activation tensor."""
+    out = {}
+    for name, t in layers.items():
+        a = t.detach().numpy()
+        if a.ndim == 4:
+            out[name + ".shape"] = np.array(a.shape)
+            out[name + ".chan_mean"] = a.mean(axis=(2, 3))                       # [B,64]
+            out[name + ".corner"] = a[PROBE, :, :3, :3].copy()                   # ring + first interior values
+            out[name + ".row_mid"] = a[PROBE, :, a.shape[2] // 2, :].copy()      # one full row
+            out[name + ".col1"] = a[PROBE, :, :, 1].copy()                       # one full column
+        else:
+            out[name] = a.copy()
+    return out
+
+
+def dscnn_golden():
+    torch.manual_seed(1234)
+    rs = np.random.RandomState(7)
+    x_rand = torch.from_numpy(rs.standard_normal((3, 1, 99, 10)).astype(np.float32))
+    clips, _ = make_clips()
+    x_mfcc = torch.from_numpy(o_mfcc.collate_pcm16(clips[[0, 3, 4, 5]]))         # realistic feature ranges incl. silence
+    x = torch.cat([x_rand, x_mfcc], 0)
+
+    save = {"x": x.numpy()}
+    # (a) every parameter N(0, 0.1), biases included  (b) the reference's own default init, seed 0
+    torch.manual_seed(0)
+    ref_default = ref_models.DepthwiseSeparableConv(num_classes=12).eval()
+    states = {
+        "n01": o_dscnn.random_state(seed=1, std=0.1),
+        "default": {k: v.detach().clone() for k, v in ref_default.state_dict().items()},
+    }
+    assert list(ref_default.state_dict().keys()) == o_dscnn.STATE_KEYS
+    for tag, st in states.items():
+        ref = ref_models.DepthwiseSeparableConv(num_classes=12).eval()
+        ref.load_state_dict(st)
+        with torch.no_grad():
+            # reference forward with per-layer captures via the module's own submodules
+            h = torch.relu(ref.conv1(x)); layers = {"conv1": h}
+            for i, blk in enumerate([ref.dsconv1, ref.dsconv2, ref.dsconv3, ref.dsconv4], 1):
+                d = blk.depthwise(h); layers[f"dsconv{i}.depthwise"] = d
+                h = blk(h); layers[f"dsconv{i}"] = h
+            logits = ref(x)
+            o_logits, o_layers = o_dscnn.forward(st, x, return_layers=True)
+        np.testing.assert_allclose(o_logits.numpy(), logits.numpy(), rtol=0, atol=1e-6)
+        for name, t in layers.items():
+            np.testing.assert_allclose(o_layers[name].numpy(), t.numpy(), rtol=0, atol=2e-6 * max(1.0, float(t.abs().max())))
+        save[f"{tag}.blob"] = o_dscnn.flatten_state(st)
+        save[f"{tag}.logits"] = logits.numpy()
+        save[f"{tag}.label"] = torch.max(logits, 1)[1].numpy()
+        for k, v in probe_layers(layers).items():
+            save[f"{tag}.{k}"] = v
+        print(tag, "logits[0] =", np.round(logits[0].numpy(), 4))
+    np.savez_compressed(os.path.join(HERE, "dscnn_golden.npz"), **save)
+    print("dscnn_golden.npz written")
+
+
+if __name__ == "__main__":
+    sigproc_golden()
+    dscnn_golden()

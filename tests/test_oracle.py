@@ -1,0 +1,186 @@
+"""CPU tests: pin the oracle.
+
+1. against the golden vectors generated from the reference's importable modules
+   (tests/golden/make_golden.py): pre-emphasis, framing, power spectrum, DS-CNN;
+2. against the recipe of the reference's own unit test
+   (tests/kws/libs/speech_features/test_sigproc.py:8-21, rtol 1e-5 / atol 1e-8);
+3. analytic known answers for the psf-only tail, which no reference-held
+   vector covers (PARITY UNPINNED for mel/log/DCT/lifter/energy).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+from scipy.fftpack import dct
+
+from oracle import dscnn as o_dscnn
+from oracle import psf_mfcc as o
+
+SPEC = o.DEFAULT_SPEC
+
+
+# ------------------------------------------------------------------ golden: sigproc
+def test_spec_defaults_match_audio_config():
+    assert (SPEC.frame_len, SPEC.frame_step, SPEC.nfft, SPEC.n_bins) == (400, 160, 512, 257)
+    assert SPEC.num_frames == 99 and SPEC.nfilt == 26 and SPEC.numcep == 10
+
+
+def test_preemphasis_bit_exact_float32(sigproc_golden):
+    g = sigproc_golden
+    for clip, head in zip(g["clips"], g["preemph_head_f32"]):
+        y = o.preemphasis(o.pcm16_to_float(clip), 0.97)
+        assert y.dtype == np.float32
+        assert np.array_equal(y[:64], head)
+
+
+def test_powspec_matches_reference(sigproc_golden):
+    g = sigproc_golden
+    keep = g["keep_frames"]
+    for clip, ps_ref, en_ref in zip(g["clips"], g["powspec_f64"], g["frame_energy_f64"]):
+        y = o.preemphasis(o.pcm16_to_float(clip), 0.97)
+        frames = o.framesig(y, 400, 160)
+        assert frames.shape == (99, 400) and frames.dtype == np.float64
+        ps = o.powspec(frames, 512)
+        scale = max(ps_ref.max(), 1e-300)
+        np.testing.assert_allclose(ps[keep], ps_ref, rtol=1e-9, atol=1e-12 * scale)
+        np.testing.assert_allclose(ps.sum(1), en_ref, rtol=1e-9, atol=1e-12 * scale)
+
+
+def test_reference_unit_test_recipe(sigproc_golden):
+    g = sigproc_golden
+    np.random.seed(0)
+    sig = np.random.rand(16000)
+    mag = o.magspec(o.framesig(sig, 400, 160), 512)
+    np.testing.assert_allclose(mag[g["keep_frames"]], g["reftest_magspec_f64"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(mag.sum(0), g["reftest_magspec_colsum_f64"], rtol=1e-9)
+
+
+def test_framing_tail_is_zero_padded():
+    sig = np.arange(1, 16001, dtype=np.float64)
+    fr = o.framesig(sig, 400, 160)
+    assert fr.shape == (99, 400)
+    assert np.array_equal(fr[98, :320], sig[15680:]) and np.all(fr[98, 320:] == 0)  # 80 trailing zeros
+    assert np.array_equal(fr[1], sig[160:560])
+    assert o.framesig(sig[:300], 400, 160).shape == (1, 400)  # shorter than a frame -> 1 frame
+
+
+def test_fix_length_and_pcm_scale():
+    x = np.array([-32768, -1, 0, 1, 32767], np.int16)
+    f = o.pcm16_to_float(x)
+    assert f.dtype == np.float32 and f[0] == -1.0 and f[4] == np.float32(32767 / 32768)
+    assert np.array_equal(o.fix_length(f, 3), f[:3])
+    assert np.array_equal(o.fix_length(f, 7), np.concatenate([f, np.zeros(2, np.float32)]))
+
+
+# ------------------------------------------------------------------ analytic KATs (psf tail, unpinned)
+MEL_BINS = [0, 2, 4, 7, 10, 13, 16, 20, 24, 29, 34, 40, 46, 53, 60, 68, 77, 87, 97, 109, 122, 136, 152, 169, 188, 209, 231, 256]
+LIFTER = [1, 2.565463, 4.099058, 5.569565, 6.947049, 8.203468, 9.313245, 10.253789, 11.005952, 11.554423]
+
+
+def test_mel_bin_edges_and_filterbank_shape():
+    b = o.mel_bin_edges(26, 512, 16000)
+    assert b.astype(int).tolist() == MEL_BINS  # SURVEY.md section 8 a5 [probe]
+    fb = o.get_filterbanks(26, 512, 16000)
+    assert fb.shape == (26, 257)
+    assert np.count_nonzero(fb) == 459
+    assert np.all(fb[:, 0] == 0) and np.all(fb[:, 256] == 0)  # bins 0 and 256 feed no filter
+    assert np.all(np.count_nonzero(fb, axis=0) <= 2)          # every bin feeds at most two filters
+    for j in range(26):  # each triangle peaks at exactly 1.0 on its centre bin
+        assert fb[j, MEL_BINS[j + 1]] == 1.0
+        assert np.all(fb[j, : MEL_BINS[j]] == 0) and np.all(fb[j, MEL_BINS[j + 2]:] == 0)
+
+
+def test_lifter_vector():
+    np.testing.assert_allclose(o.lifter_vector(10, 22), LIFTER, atol=5e-7)
+    assert np.array_equal(o.lifter_vector(10, 0), np.ones(10))
+
+
+def test_dct_matrix_equals_scipy():
+    x = np.random.RandomState(3).standard_normal((5, 26))
+    m = o.dct2_ortho_matrix(26, 10)
+    np.testing.assert_allclose(x @ m.T, dct(x, type=2, axis=1, norm="ortho")[:, :10], atol=1e-13)
+
+
+def test_all_zero_clip_known_answer():
+    feat = o.extract_features_pcm16(np.zeros(16000, np.int16))
+    assert feat.shape == (99, 10) and feat.dtype == np.float64
+    assert np.all(feat[:, 0] == math.log(o.EPS))                 # log(eps) = -36.04365338911715
+    assert feat[0, 0] == pytest.approx(-36.04365338911715, abs=1e-13)
+    np.testing.assert_allclose(feat[:, 1:], 0.0, atol=1e-12)     # constant log-mel vector -> DCT k>=1 vanishes
+
+
+def test_mfcc_equals_explicit_matrix_form():
+    """mfcc() == log-energy + (DCT x lifter) matrix applied to log mel energies."""
+    clip = np.random.default_rng(5).integers(-32768, 32768, 16000, dtype=np.int16)
+    x = o.pcm16_to_float(clip)
+    feat, energy = o.fbank(x)
+    m = o.dct2_ortho_matrix(26, 10) * o.lifter_vector(10, 22)[:, None]
+    want = np.log(feat) @ m.T
+    want[:, 0] = np.log(energy)
+    np.testing.assert_allclose(o.mfcc(x), want, atol=1e-11)
+
+
+def test_impulse_spectrum_is_flat():
+    """A single impulse inside a frame gives |X[k]|^2 = a^2 for every bin."""
+    clip = np.zeros(16000, np.int16)
+    clip[8100] = 16384
+    x = o.preemphasis(o.pcm16_to_float(clip), 0.0)  # no pre-emphasis: pure impulse
+    ps = o.powspec(o.framesig(x, 400, 160), 512)
+    f = 8100 // 160
+    np.testing.assert_allclose(ps[f], (0.5 ** 2) / 512, rtol=1e-12)
+
+
+def test_collate_contract():
+    clips = np.random.default_rng(2).integers(-2000, 2000, (3, 16000), dtype=np.int16)
+    batch = o.collate_pcm16(clips)
+    assert batch.shape == (3, 1, 99, 10) and batch.dtype == np.float32
+    np.testing.assert_array_equal(batch[1, 0], o.extract_features_pcm16(clips[1]).astype(np.float32))
+
+
+# ------------------------------------------------------------------ golden: DS-CNN
+@pytest.mark.parametrize("tag", ["n01", "default"])
+def test_dscnn_matches_reference(dscnn_golden, tag):
+    g = dscnn_golden
+    blob = g[f"{tag}.blob"]
+    assert blob.shape == (26444,)
+    state, off = {}, 0
+    for k, shp in o_dscnn.state_shapes(12).items():
+        n = int(np.prod(shp))
+        state[k] = torch.from_numpy(blob[off:off + n].reshape(shp).copy())
+        off += n
+    x = torch.from_numpy(g["x"])
+    logits, layers = o_dscnn.forward(state, x, return_layers=True)
+    np.testing.assert_allclose(logits.numpy(), g[f"{tag}.logits"], rtol=0, atol=1e-6)
+    assert np.array_equal(o_dscnn.predict(logits).numpy(), g[f"{tag}.label"])
+    probe = [0, 4]
+    for name, t in layers.items():
+        if t.ndim != 4:
+            continue
+        a = t.numpy()
+        assert list(a.shape) == g[f"{tag}.{name}.shape"].tolist()
+        tol = 2e-6 * max(1.0, float(np.abs(a).max()))
+        np.testing.assert_allclose(a.mean(axis=(2, 3)), g[f"{tag}.{name}.chan_mean"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, :3, :3], g[f"{tag}.{name}.corner"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, a.shape[2] // 2, :], g[f"{tag}.{name}.row_mid"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, :, 1], g[f"{tag}.{name}.col1"], atol=tol)
+
+
+def test_dscnn_shapes_and_relu_bias_ring():
+    st = o_dscnn.random_state(seed=3)
+    x = torch.randn(2, 1, 99, 10)
+    logits, layers = o_dscnn.forward(st, x, return_layers=True)
+    assert logits.shape == (2, 12)
+    assert [tuple(layers[f"dsconv{i}"].shape[2:]) for i in range(1, 5)] == [(49, 5), (51, 7), (53, 9), (55, 11)]
+    assert tuple(layers["conv1"].shape[1:]) == (64, 47, 3)
+    for i in range(1, 5):  # the ring a 1x1 conv with padding=1 adds is exactly relu(bias)
+        z = layers[f"dsconv{i}"]
+        ring = torch.relu(st[f"dsconv{i}.pointwise.bias"])
+        assert torch.equal(z[0, :, 0, :], ring[:, None].expand(-1, z.shape[3]))
+        assert torch.equal(z[1, :, :, -1], ring[:, None].expand(-1, z.shape[2]))
+
+
+def test_dscnn_double_precision_agrees():
+    st = o_dscnn.random_state(seed=4)
+    x = torch.randn(4, 1, 99, 10)
+    np.testing.assert_allclose(o_dscnn.forward(st, x).numpy(), o_dscnn.forward(st, x.double()).numpy(), atol=5e-6)
