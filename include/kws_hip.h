@@ -1,0 +1,160 @@
+/*
+ * kws_hip.h -- C ABI of libkws_hip.so, the MI355X (gfx950) keyword-spotting hot path:
+ *
+ *     int16 PCM [B, n_samples]  ->  MFCC float32 [B,1,frames,numcep]  ->  DS-CNN  ->  logits [B,C], label [B]
+ *
+ * The reference (z430/keyword-spotting) is pure Python and has no FFI/plugin layer; its boundary for
+ * this path is a handful of Python callables.  Each entry point below names the reference interface
+ * it replaces (paths relative to the reference repo).  The reference-side binding is a ctypes stub,
+ * shown in INTEGRATION.md; the build's own host mirror of the reference classes lives in
+ * keyword-spotting_amd/kws/.
+ *
+ * Conventions
+ *   - every function returns KWS_OK (0) or a negative KWS_E* code; no exception crosses the ABI;
+ *     kws_last_error() gives the message of the last failure on that context.
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch-ROCm tensor.data_ptr());
+ *     the library never frees or retains them after the call's work has drained (kws_sync).
+ *   - all work is enqueued asynchronously on the context's HIP stream.
+ *   - a context belongs to one GPU and is not thread-safe; contexts are independent (one per GPU,
+ *     no collectives: utterances are independent end to end).
+ *   - there is NO CPU fallback: without a usable HIP device kws_create fails with KWS_EHIP.
+ */
+#ifndef KWS_HIP_H
+#define KWS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kws_ctx kws_ctx;
+
+enum {
+    KWS_OK = 0,
+    KWS_EINVAL = -1,       /* bad argument (null pointer, non-positive size, ...) */
+    KWS_ENOMEM = -2,       /* host or device allocation failed */
+    KWS_EHIP = -3,         /* a HIP runtime call failed (message in kws_last_error) */
+    KWS_ESTATE = -4,       /* front end / model not configured yet */
+    KWS_EUNSUPPORTED = -5  /* configuration outside what the gfx950 kernels implement */
+};
+
+/* ABI version of this header; kws_abi_version() returns the library's. */
+#define KWS_ABI_VERSION 1
+int kws_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Create a context on GPU `device_id` with its own non-blocking HIP stream and the default front
+ * end (kws_set_frontend defaults).  Replaces the implicit device selection of
+ * kws/libs/models.py:67 and kws/libs/data_loader.py:63 (`torch.device("cuda" ...)`). */
+int kws_create(kws_ctx** out, int device_id);
+void kws_destroy(kws_ctx* ctx);
+
+/* Enqueue on the caller's stream instead (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL returns to the context's own stream. */
+int kws_set_stream(kws_ctx* ctx, void* hip_stream);
+
+/* Block the host until everything enqueued on the context's stream has finished. */
+int kws_sync(kws_ctx* ctx);
+
+/* Message of the last failure on this context ("" if none).  ctx == NULL: message of the last
+ * failed kws_create on this thread. */
+const char* kws_last_error(kws_ctx* ctx);
+
+/* ---- front end: AudioProcessor.extract_features (kws/libs/audio_processor.py:235-278) ------- */
+
+/* Parameters of psf.mfcc as the reference calls it.  Defaults (also set by kws_create):
+ *   sample_rate 16000, n_samples 16000, frame_len 400, frame_step 160, nfft 512, nfilt 26,
+ *   numcep 10, preemph 0.97, ceplifter 22                     (AudioConfig, audio_processor.py:37-46;
+ *   psf.mfcc defaults for preemph / ceplifter / lowfreq 0 / highfreq sr/2 / appendEnergy True /
+ *   rectangular window).  frame_len and frame_step are in samples (winlen*sr, winstep*sr rounded
+ *   half up, as psf does).  Supported by the kernels: nfft == 512, frame_len <= 512, nfilt <= 64,
+ *   numcep <= min(nfilt, 32); anything else returns KWS_EUNSUPPORTED. */
+int kws_set_frontend(kws_ctx* ctx, int sample_rate, int n_samples, int frame_len, int frame_step,
+                     int nfft, int nfilt, int numcep, float preemph, int ceplifter);
+
+/* Frames per clip (1 + ceil((n_samples - frame_len)/frame_step), sigproc.py:31-35) and numcep. */
+int kws_frontend_shape(kws_ctx* ctx, int* num_frames, int* numcep);
+
+/* Batched MFCC.  d_wav: int16 [B, n_samples] (PCM as stored in a 16-bit WAV; the kernel applies the
+ * x/32768 scaling librosa.load applies, audio_processor.py:145).  d_out: float32
+ * [B, 1, num_frames, numcep] -- the collated batch of SpeechCommandsDataLoader.__getitem__
+ * (kws/libs/data_loader.py:96-105: float32 cast + channel axis) stacked by torch default_collate. */
+int kws_mfcc_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_out);
+
+/* Same, for a float32 signal in [-1, 1] that the caller has already decoded and possibly augmented
+ * (time shift / background noise, audio_processor.py:154-159): d_wav float32 [B, n_samples].  This is
+ * the exact input type of AudioProcessor.extract_features(signal) (audio_processor.py:235). */
+int kws_mfcc_f32(kws_ctx* ctx, const float* d_wav, int B, float* d_out);
+
+/* ---- model: DepthwiseSeparableConv (kws/libs/models.py:122-183) ----------------------------- */
+
+/* Load weights: `blob` is a HOST pointer to the 20 state_dict tensors concatenated in state_dict
+ * order (conv1.weight, conv1.bias, dsconv{1..4}.{depthwise,pointwise}.{weight,bias}, fc.weight,
+ * fc.bias), float32; n_floats must be 25664 + 65*num_classes.  Copied to the device; the caller
+ * keeps ownership.  Replaces KeywordSpottingModel.load (models.py:55-72). */
+int kws_load_dscnn(kws_ctx* ctx, const float* blob, size_t n_floats, int num_classes);
+
+/* Forward on precomputed features.  d_feat: float32 [B,1,99,10]; d_logits: float32
+ * [B,num_classes]; d_label: int32 [B] = argmax (first maximum wins, torch.max semantics,
+ * kws/libs/training.py:371) or NULL.  Replaces DepthwiseSeparableConv.forward (models.py:160-183). */
+int kws_forward_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
+
+/* Fused wav -> label: kws_mfcc_i16 into an internal workspace, then kws_forward_f32.  This is the
+ * shape of inference(wav) -> label (kws/inference/inference_local.py:67-81), batched. */
+int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label);
+
+/* Pre-size the internal workspaces for batches up to max_batch (otherwise grown on demand, which
+ * allocates and must not happen inside stream capture). */
+int kws_reserve(kws_ctx* ctx, int max_batch);
+
+/* Debug/parity aid: run the DS-CNN and also store every stored activation per clip to d_act
+ * (float32 [B, KWS_ACT_FLOATS_PER_CLIP]): conv1 out [64][47*3], block1 out interior [64][47*3],
+ * block2 out interior [64][49*5], block3 out interior [64][51*7], pooled mean [64].  "Interior" =
+ * the pointwise output without the relu(bias) ring its padding=1 adds (models.py:104-106). */
+#define KWS_ACT_FLOATS_PER_CLIP (64 * (141 + 141 + 245 + 357) + 64)
+int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label,
+                          float* d_act, int use_mfma);
+
+/* ---- sigproc operators (kws/libs/speech_features/sigproc.py) -------------------------------- */
+
+/* preemphasis(signal, coeff) (sigproc.py:93-103), float32 [n] -> float32 [n]. */
+int kws_preemphasis_f32(kws_ctx* ctx, const float* d_signal, int n, float coeff, float* d_out);
+/* framesig(signal, frame_len, frame_step, winfunc) (sigproc.py:14-52): d_window float32 [frame_len]
+ * or NULL for rectangular; d_frames float32 [num_frames, frame_len], num_frames as kws_frontend_shape. */
+int kws_framesig_f32(kws_ctx* ctx, const float* d_signal, int n, int frame_len, int frame_step,
+                     const float* d_window, float* d_frames);
+/* magspec / powspec (sigproc.py:55-90) with NFFT = 512: d_frames float32 [num_frames, frame_len]
+ * (frame_len <= 512 is zero-padded, > 512 truncated) -> float32 [num_frames, 257];
+ * power != 0 gives 1/NFFT * |X|^2, power == 0 gives |X|. */
+int kws_spec512_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int frame_len, int power,
+                    float* d_spec);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+/* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
+ * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
+ * launch count per kernel id since the last kws_prof_reset. */
+enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_COUNT = 2 };
+int kws_prof_enable(kws_ctx* ctx, int on);
+int kws_prof_reset(kws_ctx* ctx);
+int kws_prof_read(kws_ctx* ctx, int kernel_id, double* total_ms, int* launches);
+/* Name of the device kernel behind a kernel id (as it appears in rocprofv3 traces). */
+const char* kws_kernel_name(int kernel_id);
+
+/* ---- host-only helpers (no GPU needed; used by the CPU test-suite) -------------------------- */
+
+/* nfilt+2 mel bin edges exactly as psf get_filterbanks computes them. */
+int kws_host_mel_edges(int nfilt, int nfft, int sample_rate, int* edges_out);
+/* Dense float32 [nfilt, nfft/2+1] filterbank expanded from the sparse per-lane tables the kernel
+ * uses (so the sparse decomposition can be checked against the oracle's dense matrix on CPU). */
+int kws_host_mel_dense(int nfilt, int nfft, int sample_rate, float* fb_out);
+/* float32 [numcep, nfilt] DCT-II(ortho) x lifter table the kernel uses. */
+int kws_host_dct_lifter(int nfilt, int numcep, int ceplifter, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWS_HIP_H */

@@ -1,0 +1,592 @@
+// C ABI of libkws_hip.so (declared in include/kws_hip.h): context, host-side table construction,
+// weight repacking, workspace and per-kernel event timing.  No torch types, no exceptions across the
+// boundary, no CPU fallback.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "kws_internal.h"
+
+namespace kws {
+
+const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel"};
+
+// ------------------------------------------------------------------------------------------------
+// Host tables (double precision, then rounded once to float32).
+
+static double hz2mel(double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); }
+static double mel2hz(double mel) { return 700.0 * (std::pow(10.0, mel / 2595.0) - 1.0); }
+
+// psf get_filterbanks: nfilt+2 points equally spaced in mel (numpy.linspace arithmetic: i*step + start,
+// last point = stop), converted to FFT bins by floor((nfft+1)*hz/samplerate).
+static void mel_edges(int nfilt, int nfft, int sample_rate, std::vector<int>& edges) {
+    const double lowmel = hz2mel(0.0), highmel = hz2mel(sample_rate / 2.0);
+    const int num = nfilt + 2;
+    const double step = (highmel - lowmel) / (double)(num - 1);
+    edges.resize(num);
+    for (int i = 0; i < num; ++i) {
+        volatile double prod = (double)i * step;  // two roundings, as numpy does (no fused multiply-add)
+        double mel = prod + lowmel;
+        if (i == num - 1) mel = highmel;
+        edges[i] = (int)std::floor((nfft + 1) * mel2hz(mel) / sample_rate);
+    }
+}
+
+bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::string& err) {
+    if (nfilt < 1 || nfilt > MAX_NFILT) {
+        err = "nfilt must be in [1, 64]";
+        return false;
+    }
+    mel_edges(nfilt, nfft, sample_rate, out.edges);
+    for (int i = 0; i + 1 < (int)out.edges.size(); ++i) {
+        if (out.edges[i + 1] < out.edges[i] || out.edges[i] < 0 || out.edges[i + 1] > nfft / 2) {
+            err = "mel edges are not monotone inside [0, nfft/2]";
+            return false;
+        }
+    }
+    out.k0.assign(64, nfft / 2);
+    out.rw.assign(MEL_CHUNK * 64, 0.f);
+    out.fw.assign(MEL_CHUNK * 64, 0.f);
+    out.gather.assign(64, 0u);
+    std::vector<int> seg_first(nfilt + 2, 0), seg_count(nfilt + 2, 0);
+    int nchunks = 0;
+    // segment s = bins [edge_s, edge_s+1): rising side of filter s (s < nfilt), falling side of filter s-1 (s >= 1)
+    for (int s = 0; s <= nfilt; ++s) {
+        const int lo = out.edges[s], hi = out.edges[s + 1];
+        seg_first[s] = nchunks;
+        for (int k0 = lo; k0 < hi; k0 += MEL_CHUNK) {
+            if (nchunks >= 64) {
+                err = "mel filterbank needs more than 64 chunks of 8 bins";
+                return false;
+            }
+            out.k0[nchunks] = k0;
+            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) {
+                const double k = k0 + i, width = (double)(hi - lo);
+                if (s < nfilt) out.rw[i * 64 + nchunks] = (float)((k - lo) / width);
+                if (s >= 1) out.fw[i * 64 + nchunks] = (float)((hi - k) / width);
+            }
+            ++nchunks;
+        }
+        seg_count[s] = nchunks - seg_first[s];
+    }
+    for (int j = 0; j < nfilt; ++j) {
+        if (seg_count[j] > 255 || seg_count[j + 1] > 255) {
+            err = "mel segment too long";
+            return false;
+        }
+        out.gather[j] = (uint32_t)seg_first[j] | ((uint32_t)seg_count[j] << 8) | ((uint32_t)seg_first[j + 1] << 16) |
+                        ((uint32_t)seg_count[j + 1] << 24);
+    }
+    out.n_chunks = nchunks;
+    return true;
+}
+
+void build_dct_lifter_host(int nfilt, int numcep, int ceplifter, std::vector<float>& out) {
+    out.assign((size_t)numcep * nfilt, 0.f);
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < numcep; ++i) {
+        const double lift = ceplifter > 0 ? 1.0 + (ceplifter / 2.0) * std::sin(pi * i / ceplifter) : 1.0;
+        for (int j = 0; j < nfilt; ++j) {
+            const double d = (i == 0) ? std::sqrt(1.0 / nfilt)
+                                      : std::sqrt(2.0 / nfilt) * std::cos(pi * i * (2 * j + 1) / (2.0 * nfilt));
+            out[(size_t)i * nfilt + j] = (float)(lift * d);
+        }
+    }
+}
+
+void build_twiddle_host(std::vector<float2>& out) {
+    out.resize(NFFT);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < NFFT; ++k) {
+        const double a = 2.0 * pi * k / NFFT;
+        out[k] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+    }
+}
+
+}  // namespace kws
+
+using namespace kws;
+
+// ------------------------------------------------------------------------------------------------
+struct kws_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // front end
+    int sample_rate = 16000, nfft = NFFT, ceplifter = 22;
+    FrontendParams fp{};
+    bool fe_ready = false;
+    void* d_fe = nullptr;  // one allocation holding all front-end tables
+    FrontendTables ft{};
+
+    // model
+    float* d_model = nullptr;
+    DscnnWeights mw{};
+    bool model_ready = false;
+
+    // workspace (MFCC features between the two kernels of kws_infer_i16)
+    float* d_feat_ws = nullptr;
+    size_t feat_ws_floats = 0;
+
+    // profiling
+    bool prof = false;
+    struct EvPair {
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> ev[KWS_K_COUNT];
+    size_t ev_used[KWS_K_COUNT] = {0, 0};
+    double ms_total[KWS_K_COUNT] = {0, 0};
+    long launches[KWS_K_COUNT] = {0, 0};
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(kws_ctx* c, int code, const std::string& msg) {
+    if (c)
+        c->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+static int fail_hip(kws_ctx* c, hipError_t e, const char* what) {
+    return fail(c, KWS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, expr)                                   \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return fail_hip(c, _e, #expr); \
+    } while (0)
+
+static int frames_for(int n_samples, int frame_len, int frame_step) {
+    if (n_samples <= frame_len) return 1;
+    return 1 + (n_samples - frame_len + frame_step - 1) / frame_step;  // 1 + ceil((n - L)/step)
+}
+
+// Bracket a kernel launch with events when profiling is on.
+struct ProfScope {
+    kws_ctx* c;
+    int id;
+    hipEvent_t stop = nullptr;
+    ProfScope(kws_ctx* c_, int id_) : c(c_), id(id_) {
+        if (!c->prof) return;
+        if (c->ev_used[id] == c->ev[id].size()) {
+            kws_ctx::EvPair p{};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            c->ev[id].push_back(p);
+        }
+        kws_ctx::EvPair& p = c->ev[id][c->ev_used[id]++];
+        (void)hipEventRecord(p.a, c->stream);
+        stop = p.b;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, c->stream);
+    }
+};
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int kws_abi_version(void) { return KWS_ABI_VERSION; }
+
+const char* kws_last_error(kws_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+const char* kws_kernel_name(int id) { return (id >= 0 && id < KWS_K_COUNT) ? kKernelNames[id] : ""; }
+
+int kws_create(kws_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, KWS_EINVAL, "kws_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, KWS_EHIP, std::string("kws_create: no HIP device (") + hipGetErrorString(e) + "); there is no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, KWS_EINVAL, "kws_create: device_id out of range");
+    kws_ctx* c = new (std::nothrow) kws_ctx();
+    if (!c) return fail(nullptr, KWS_ENOMEM, "kws_create: out of host memory");
+    c->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = dscnn_init_device();
+    if (e != hipSuccess) {
+        int rc = fail_hip(nullptr, e, "kws_create");
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return rc;
+    }
+    c->stream = c->own_stream;
+    int rc = kws_set_frontend(c, 16000, 16000, 400, 160, 512, 26, 10, 0.97f, 22);
+    if (rc != KWS_OK) {
+        g_create_err = c->err;
+        kws_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return KWS_OK;
+}
+
+void kws_destroy(kws_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < KWS_K_COUNT; ++k)
+        for (auto& p : c->ev[k]) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+    if (c->d_fe) (void)hipFree(c->d_fe);
+    if (c->d_model) (void)hipFree(c->d_model);
+    if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int kws_set_stream(kws_ctx* c, void* hip_stream) {
+    if (!c) return KWS_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return KWS_OK;
+}
+
+int kws_sync(kws_ctx* c) {
+    if (!c) return KWS_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return KWS_OK;
+}
+
+int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, int frame_step, int nfft, int nfilt,
+                     int numcep, float preemph, int ceplifter) {
+    if (!c) return KWS_EINVAL;
+    if (sample_rate <= 0 || n_samples <= 0 || frame_len <= 0 || frame_step <= 0 || nfilt <= 0 || numcep <= 0)
+        return fail(c, KWS_EINVAL, "kws_set_frontend: sizes must be positive");
+    if (nfft != NFFT) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: only nfft == 512 is implemented");
+    if (frame_len > NFFT) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: frame_len must be <= 512");
+    if (nfilt > MAX_NFILT || numcep > MAX_NUMCEP || numcep > nfilt)
+        return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: need nfilt <= 64 and numcep <= min(nfilt, 32)");
+    MelHost mel;
+    std::string err;
+    if (!build_mel_host(nfilt, nfft, sample_rate, mel, err)) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: " + err);
+    std::vector<float> dct;
+    build_dct_lifter_host(nfilt, numcep, ceplifter, dct);
+    std::vector<float2> tw;
+    build_twiddle_host(tw);
+
+    // one device allocation: twiddle | k0 | rw | fw | gather | dct   (each 256-byte aligned)
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
+                 o_fw = al(o_rw + sizeof(float) * MEL_CHUNK * 64), o_g = al(o_fw + sizeof(float) * MEL_CHUNK * 64),
+                 o_dct = al(o_g + sizeof(uint32_t) * 64), total = al(o_dct + sizeof(float) * dct.size());
+    std::vector<unsigned char> host(total, 0);
+    memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
+    memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
+    memcpy(&host[o_rw], mel.rw.data(), sizeof(float) * MEL_CHUNK * 64);
+    memcpy(&host[o_fw], mel.fw.data(), sizeof(float) * MEL_CHUNK * 64);
+    memcpy(&host[o_g], mel.gather.data(), sizeof(uint32_t) * 64);
+    memcpy(&host[o_dct], dct.data(), sizeof(float) * dct.size());
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
+    void* d = nullptr;
+    if (hipMalloc(&d, total) != hipSuccess) return fail(c, KWS_ENOMEM, "kws_set_frontend: device allocation failed");
+    hipError_t e = hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(c, e, "kws_set_frontend: hipMemcpy");
+    }
+    if (c->d_fe) (void)hipFree(c->d_fe);
+    c->d_fe = d;
+    unsigned char* b = static_cast<unsigned char*>(d);
+    c->ft.twiddle = reinterpret_cast<const float2*>(b + o_tw);
+    c->ft.mel_k0 = reinterpret_cast<const int*>(b + o_k0);
+    c->ft.mel_rw = reinterpret_cast<const float*>(b + o_rw);
+    c->ft.mel_fw = reinterpret_cast<const float*>(b + o_fw);
+    c->ft.mel_gather = reinterpret_cast<const uint32_t*>(b + o_g);
+    c->ft.dct = reinterpret_cast<const float*>(b + o_dct);
+
+    FrontendParams& p = c->fp;
+    p.n_samples = n_samples;
+    p.frame_len = frame_len;
+    p.frame_step = frame_step;
+    p.num_frames = frames_for(n_samples, frame_len, frame_step);
+    p.nfilt = nfilt;
+    p.numcep = numcep;
+    p.append_energy = 1;
+    p.preemph = preemph;
+    p.chunk_samples = (2 * MFCC_PAIRS - 1) * frame_step + frame_len;
+    // 16-byte PCM loads: every clip base, every workgroup's first sample and the staged length must be
+    // multiples of 8 samples (the pointer itself is checked per call)
+    p.vec_ok = (n_samples % 8 == 0) && ((2 * MFCC_PAIRS * frame_step) % 8 == 0) && (p.chunk_samples % 8 == 0);
+    c->sample_rate = sample_rate;
+    c->ceplifter = ceplifter;
+    c->fe_ready = true;
+    return KWS_OK;
+}
+
+int kws_frontend_shape(kws_ctx* c, int* num_frames, int* numcep) {
+    if (!c) return KWS_EINVAL;
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "front end not configured");
+    if (num_frames) *num_frames = c->fp.num_frames;
+    if (numcep) *numcep = c->fp.numcep;
+    return KWS_OK;
+}
+
+int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_classes) {
+    if (!c) return KWS_EINVAL;
+    if (!blob) return fail(c, KWS_EINVAL, "kws_load_dscnn: blob is NULL");
+    if (num_classes < 1 || num_classes > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_load_dscnn: num_classes must be in [1, 64]");
+    const size_t expect = 6400 + 64 + 4 * (576 + 64 + 4096 + 64) + (size_t)num_classes * 64 + num_classes;
+    if (n_floats != expect) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "kws_load_dscnn: expected %zu floats for %d classes, got %zu", expect, num_classes, n_floats);
+        return fail(c, KWS_EINVAL, msg);
+    }
+    // repack: c1_w [100][64] | c1_b [64] | dw [4][64][12] | pw_w [4][cin][cout] | pw_b [4][64] | fc_w | fc_b
+    const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
+                 o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64, total = o_fcb + num_classes;
+    std::vector<float> h(total, 0.f);
+    const float* src = blob;
+    for (int co = 0; co < 64; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
+        for (int k = 0; k < 100; ++k) h[o_c1w + (size_t)k * 64 + co] = src[co * 100 + k];
+    src += 6400;
+    memcpy(&h[o_c1b], src, 64 * sizeof(float));
+    src += 64;
+    for (int b = 0; b < 4; ++b) {
+        const float *dw_w = src, *dw_b = src + 576, *pw_w = src + 640, *pw_b = src + 640 + 4096;
+        for (int ch = 0; ch < 64; ++ch) {
+            for (int t = 0; t < 9; ++t) h[o_dw + ((size_t)b * 64 + ch) * 12 + t] = dw_w[ch * 9 + t];
+            h[o_dw + ((size_t)b * 64 + ch) * 12 + 9] = dw_b[ch];
+        }
+        for (int co = 0; co < 64; ++co)  // pointwise.weight [cout][cin][1][1] -> [cin][cout]
+            for (int ci = 0; ci < 64; ++ci) h[o_pww + (size_t)b * 4096 + (size_t)ci * 64 + co] = pw_w[co * 64 + ci];
+        memcpy(&h[o_pwb + (size_t)b * 64], pw_b, 64 * sizeof(float));
+        src += 576 + 64 + 4096 + 64;
+    }
+    memcpy(&h[o_fcw], src, (size_t)num_classes * 64 * sizeof(float));
+    src += (size_t)num_classes * 64;
+    memcpy(&h[o_fcb], src, (size_t)num_classes * sizeof(float));
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), total * sizeof(float)) != hipSuccess)
+        return fail(c, KWS_ENOMEM, "kws_load_dscnn: device allocation failed");
+    hipError_t e = hipMemcpy(d, h.data(), total * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(c, e, "kws_load_dscnn: hipMemcpy");
+    }
+    if (c->d_model) (void)hipFree(c->d_model);
+    c->d_model = d;
+    c->mw.c1_w = d + o_c1w;
+    c->mw.c1_b = d + o_c1b;
+    c->mw.dw_w = d + o_dw;
+    c->mw.pw_w = d + o_pww;
+    c->mw.pw_b = d + o_pwb;
+    c->mw.fc_w = d + o_fcw;
+    c->mw.fc_b = d + o_fcb;
+    c->mw.num_classes = num_classes;
+    c->model_ready = true;
+    return KWS_OK;
+}
+
+int kws_reserve(kws_ctx* c, int max_batch) {
+    if (!c) return KWS_EINVAL;
+    if (max_batch <= 0) return fail(c, KWS_EINVAL, "kws_reserve: max_batch must be positive");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "front end not configured");
+    const size_t need = (size_t)max_batch * c->fp.num_frames * c->fp.numcep;
+    if (need <= c->feat_ws_floats) return KWS_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), need * sizeof(float)) != hipSuccess)
+        return fail(c, KWS_ENOMEM, "kws_reserve: device allocation failed");
+    if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
+    c->d_feat_ws = d;
+    c->feat_ws_floats = need;
+    return KWS_OK;
+}
+
+static int check_batch(kws_ctx* c, const void* in, int B, const char* fn) {
+    if (!c) return KWS_EINVAL;
+    if (!in) return fail(c, KWS_EINVAL, std::string(fn) + ": input pointer is NULL");
+    if (B <= 0) return fail(c, KWS_EINVAL, std::string(fn) + ": B must be positive");
+    return KWS_OK;
+}
+
+int kws_mfcc_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_out) {
+    int rc = check_batch(c, d_wav, B, "kws_mfcc_i16");
+    if (rc) return rc;
+    if (!d_out) return fail(c, KWS_EINVAL, "kws_mfcc_i16: d_out is NULL");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_mfcc_i16: front end not configured");
+    HIP_TRY(c, hipSetDevice(c->device));
+    FrontendParams p = c->fp;
+    if ((reinterpret_cast<uintptr_t>(d_wav) & 15) != 0) p.vec_ok = 0;
+    ProfScope ps(c, KWS_K_MFCC);
+    HIP_TRY(c, launch_mfcc(c->stream, p, c->ft, d_wav, B, d_out));
+    return KWS_OK;
+}
+
+int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
+    int rc = check_batch(c, d_wav, B, "kws_mfcc_f32");
+    if (rc) return rc;
+    if (!d_out) return fail(c, KWS_EINVAL, "kws_mfcc_f32: d_out is NULL");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_mfcc_f32: front end not configured");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ProfScope ps(c, KWS_K_MFCC);
+    HIP_TRY(c, launch_mfcc_f32(c->stream, c->fp, c->ft, d_wav, B, d_out));
+    return KWS_OK;
+}
+
+static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
+                        bool use_mfma, const char* fn) {
+    int rc = check_batch(c, d_feat, B, fn);
+    if (rc) return rc;
+    if (!d_logits) return fail(c, KWS_EINVAL, std::string(fn) + ": d_logits is NULL");
+    if (!c->model_ready) return fail(c, KWS_ESTATE, std::string(fn) + ": no model loaded (kws_load_dscnn)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ProfScope ps(c, KWS_K_DSCNN);
+    HIP_TRY(c, launch_dscnn(c->stream, c->mw, d_feat, B, d_logits, d_label, d_act, use_mfma));
+    return KWS_OK;
+}
+
+int kws_forward_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label) {
+    return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, true, "kws_forward_f32");
+}
+
+int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
+                          int use_mfma) {
+    return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma != 0, "kws_forward_debug_f32");
+}
+
+int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label) {
+    int rc = check_batch(c, d_wav, B, "kws_infer_i16");
+    if (rc) return rc;
+    if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_i16: front end or model not configured");
+    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
+        return fail(c, KWS_EUNSUPPORTED, "kws_infer_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
+    rc = kws_reserve(c, B);
+    if (rc) return rc;
+    rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
+    if (rc) return rc;
+    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, true, "kws_infer_i16");
+}
+
+// ---- sigproc operators --------------------------------------------------------------------------
+int kws_preemphasis_f32(kws_ctx* c, const float* d_signal, int n, float coeff, float* d_out) {
+    int rc = check_batch(c, d_signal, n, "kws_preemphasis_f32");
+    if (rc) return rc;
+    if (!d_out) return fail(c, KWS_EINVAL, "kws_preemphasis_f32: d_out is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_preemphasis(c->stream, d_signal, n, coeff, d_out));
+    return KWS_OK;
+}
+
+int kws_framesig_f32(kws_ctx* c, const float* d_signal, int n, int frame_len, int frame_step, const float* d_window,
+                     float* d_frames) {
+    int rc = check_batch(c, d_signal, n, "kws_framesig_f32");
+    if (rc) return rc;
+    if (!d_frames || frame_len <= 0 || frame_step <= 0) return fail(c, KWS_EINVAL, "kws_framesig_f32: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_framesig(c->stream, d_signal, n, frame_len, frame_step, frames_for(n, frame_len, frame_step), d_window, d_frames));
+    return KWS_OK;
+}
+
+int kws_spec512_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame_len, int power, float* d_spec) {
+    int rc = check_batch(c, d_frames, num_frames, "kws_spec512_f32");
+    if (rc) return rc;
+    if (!d_spec || frame_len <= 0) return fail(c, KWS_EINVAL, "kws_spec512_f32: bad argument");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_spec512_f32: front end tables not built");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_spec512(c->stream, c->ft, d_frames, num_frames, frame_len, power, d_spec));
+    return KWS_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+int kws_prof_enable(kws_ctx* c, int on) {
+    if (!c) return KWS_EINVAL;
+    c->prof = on != 0;
+    return KWS_OK;
+}
+
+static int prof_drain(kws_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < KWS_K_COUNT; ++k) {
+        for (size_t i = 0; i < c->ev_used[k]; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev[k][i].a, c->ev[k][i].b) == hipSuccess) {
+                c->ms_total[k] += ms;
+                c->launches[k] += 1;
+            }
+        }
+        c->ev_used[k] = 0;
+    }
+    return KWS_OK;
+}
+
+int kws_prof_reset(kws_ctx* c) {
+    if (!c) return KWS_EINVAL;
+    int rc = prof_drain(c);
+    for (int k = 0; k < KWS_K_COUNT; ++k) {
+        c->ms_total[k] = 0;
+        c->launches[k] = 0;
+    }
+    return rc;
+}
+
+int kws_prof_read(kws_ctx* c, int kernel_id, double* total_ms, int* launches) {
+    if (!c) return KWS_EINVAL;
+    if (kernel_id < 0 || kernel_id >= KWS_K_COUNT) return fail(c, KWS_EINVAL, "kws_prof_read: bad kernel id");
+    int rc = prof_drain(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->ms_total[kernel_id];
+    if (launches) *launches = (int)c->launches[kernel_id];
+    return KWS_OK;
+}
+
+// ---- host-only helpers -----------------------------------------------------------------------------
+int kws_host_mel_edges(int nfilt, int nfft, int sample_rate, int* edges_out) {
+    if (!edges_out || nfilt < 1 || nfft < 2 || sample_rate < 1) return KWS_EINVAL;
+    std::vector<int> e;
+    mel_edges(nfilt, nfft, sample_rate, e);
+    memcpy(edges_out, e.data(), sizeof(int) * e.size());
+    return KWS_OK;
+}
+
+int kws_host_mel_dense(int nfilt, int nfft, int sample_rate, float* fb_out) {
+    if (!fb_out) return KWS_EINVAL;
+    MelHost mel;
+    std::string err;
+    if (!build_mel_host(nfilt, nfft, sample_rate, mel, err)) return KWS_EUNSUPPORTED;
+    const int nb = nfft / 2 + 1;
+    std::fill(fb_out, fb_out + (size_t)nfilt * nb, 0.f);
+    // expand exactly what the kernel evaluates: filter j = rising weights of its chunks + falling weights
+    // of the next segment's chunks
+    for (int j = 0; j < nfilt; ++j) {
+        const uint32_t g = mel.gather[j];
+        const int r0 = g & 255, nr = (g >> 8) & 255, q0 = (g >> 16) & 255, nq = g >> 24;
+        for (int c = r0; c < r0 + nr; ++c)
+            for (int i = 0; i < MEL_CHUNK; ++i) {
+                const int k = mel.k0[c] + i;
+                if (k < nb) fb_out[(size_t)j * nb + k] += mel.rw[i * 64 + c];
+            }
+        for (int c = q0; c < q0 + nq; ++c)
+            for (int i = 0; i < MEL_CHUNK; ++i) {
+                const int k = mel.k0[c] + i;
+                if (k < nb) fb_out[(size_t)j * nb + k] += mel.fw[i * 64 + c];
+            }
+    }
+    return KWS_OK;
+}
+
+int kws_host_dct_lifter(int nfilt, int numcep, int ceplifter, float* out) {
+    if (!out || nfilt < 1 || numcep < 1) return KWS_EINVAL;
+    std::vector<float> t;
+    build_dct_lifter_host(nfilt, numcep, ceplifter, t);
+    memcpy(out, t.data(), sizeof(float) * t.size());
+    return KWS_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,94 @@
+// Internal declarations shared by the C-ABI translation unit and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "kws_hip.h"
+
+namespace kws {
+
+// ------------------------------------------------------------------------------------------------
+// Front end (MFCC) -- one 64-lane workgroup handles MFCC_PAIRS frame pairs (2 real frames are packed
+// into one 512-point complex FFT).
+constexpr int NFFT = 512;
+constexpr int NBINS = NFFT / 2 + 1;       // 257
+constexpr int MEL_CHUNK = 8;              // bins per lane in the sparse mel stage
+constexpr int MFCC_PAIRS = 5;             // frame pairs per workgroup (10 frames)
+constexpr int MAX_NFILT = 64;
+constexpr int MAX_NUMCEP = 32;
+
+struct FrontendParams {
+    int n_samples;
+    int frame_len;
+    int frame_step;
+    int num_frames;
+    int nfilt;
+    int numcep;
+    int append_energy;
+    float preemph;
+    int chunk_samples;     // samples staged per workgroup = (2*MFCC_PAIRS-1)*frame_step + frame_len
+    int vec_ok;            // 1 -> 16-byte vector loads of PCM are legal for every workgroup
+};
+
+// Device tables of the front end (all float32 unless noted), built on the host in double.
+struct FrontendTables {
+    const float2* twiddle;     // [512]      (cos, -sin)(2*pi*k/512)
+    const int* mel_k0;         // [64]       first bin of lane's chunk (or NBINS-1 for idle lanes)
+    const float* mel_rw;       // [8][64]    rising-edge weights of the chunk's bins (0 beyond its length)
+    const float* mel_fw;       // [8][64]    falling-edge weights
+    const uint32_t* mel_gather;// [64]       per filter: r0 | nr<<8 | f0<<16 | nf<<24  (chunk ranges)
+    const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
+};
+
+// Host-side construction of the sparse mel decomposition (also used by the host-only ABI helpers).
+struct MelHost {
+    std::vector<int> edges;            // nfilt+2
+    std::vector<int> k0;               // 64
+    std::vector<float> rw, fw;         // 8*64 each, [i][lane]
+    std::vector<uint32_t> gather;      // 64
+    int n_chunks = 0;
+};
+bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::string& err);
+void build_dct_lifter_host(int nfilt, int numcep, int ceplifter, std::vector<float>& out);
+void build_twiddle_host(std::vector<float2>& out);
+
+hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTables& t,
+                       const int16_t* d_wav, int B, float* d_out);
+hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t,
+                           const float* d_wav, int B, float* d_out);
+hipError_t launch_preemphasis(hipStream_t s, const float* d_in, int n, float coeff, float* d_out);
+hipError_t launch_framesig(hipStream_t s, const float* d_in, int n, int frame_len, int frame_step,
+                           int num_frames, const float* d_window, float* d_frames);
+hipError_t launch_spec512(hipStream_t s, const FrontendTables& t, const float* d_frames, int num_frames,
+                          int frame_len, int power, float* d_spec);
+
+// ------------------------------------------------------------------------------------------------
+// DS-CNN (kws/libs/models.py:122-183) for the [1,99,10] feature map.
+constexpr int CH = 64;
+constexpr int IN_T = 99, IN_F = 10;
+constexpr int C1_K = 10, C1_H = 47, C1_W = 3;             // conv1 output 64 x 47 x 3
+constexpr int N_BLOCKS = 4;
+constexpr int MAX_CLASSES = 64;
+
+// Device weights, repacked by the host for the kernel's access patterns.
+struct DscnnWeights {
+    const float* c1_w;     // [100][64]   conv1 weight transposed: [kh*10+kw][cout]
+    const float* c1_b;     // [64]
+    const float* dw_w;     // [4][64][12] depthwise 3x3 taps [0..8], bias at [9], 2 pad
+    const float* pw_w;     // [4][64][64] pointwise transposed: [cin][cout]
+    const float* pw_b;     // [4][64]
+    const float* fc_w;     // [C][64]
+    const float* fc_b;     // [C]
+    int num_classes;
+};
+
+hipError_t dscnn_init_device();
+hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
+                        int32_t* d_label, float* d_act, bool use_mfma);
+
+extern const char* const kKernelNames[KWS_K_COUNT];
+
+}  // namespace kws

@@ -1,0 +1,249 @@
+"""ctypes binding of libkws_hip.so (C ABI: include/kws_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C keyword-spotting_amd/csrc``; if it is missing, importing this module still works (so the
+host-only classes are usable) but the first compute call raises ``KWSError`` -- loudly, never a
+silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from kws.common.errors import AudioProcessingError, KWSError, ModelError
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
+
+KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+KWS_K_MFCC, KWS_K_DSCNN = 0, 1
+ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64
+
+_c_ctx = C.c_void_p
+_i16p, _f32p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+
+# name -> (restype, argtypes): every symbol include/kws_hip.h declares
+SIGNATURES = {
+    "kws_abi_version": (C.c_int, []),
+    "kws_create": (C.c_int, [C.POINTER(_c_ctx), C.c_int]),
+    "kws_destroy": (None, [_c_ctx]),
+    "kws_set_stream": (C.c_int, [_c_ctx, C.c_void_p]),
+    "kws_sync": (C.c_int, [_c_ctx]),
+    "kws_last_error": (C.c_char_p, [_c_ctx]),
+    "kws_set_frontend": (C.c_int, [_c_ctx] + [C.c_int] * 7 + [C.c_float, C.c_int]),
+    "kws_frontend_shape": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "kws_mfcc_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p]),
+    "kws_mfcc_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p]),
+    "kws_load_dscnn": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
+    "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
+    "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
+    "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
+    "kws_preemphasis_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_float, _f32p]),
+    "kws_framesig_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
+    "kws_spec512_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
+    "kws_prof_enable": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_prof_reset": (C.c_int, [_c_ctx]),
+    "kws_prof_read": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "kws_kernel_name": (C.c_char_p, [C.c_int]),
+    "kws_host_mel_edges": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "kws_host_mel_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "kws_host_dct_lifter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Load libkws_hip.so once; raise KWSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise KWSError(
+                    f"native library missing: {LIB_PATH} (build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C keyword-spotting_amd/csrc`); there is no CPU fallback"
+                )
+            try:
+                h = C.CDLL(LIB_PATH)
+            except OSError as e:  # pragma: no cover - depends on the host
+                raise KWSError(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(h, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = h
+    return _lib
+
+
+def _ptr(t) -> int:
+    return int(t.data_ptr())
+
+
+class Context:
+    """One kws_ctx: a GPU, its stream, front-end tables, model weights, workspace."""
+
+    def __init__(self, device: int = 0, error_cls=KWSError):
+        self._h = _c_ctx()
+        self._lib = lib()
+        rc = self._lib.kws_create(C.byref(self._h), int(device))
+        if rc != KWS_OK:
+            msg = self._lib.kws_last_error(None).decode()
+            self._h = _c_ctx()
+            raise error_cls(f"kws_create failed ({rc}): {msg}")
+        self.device = int(device)
+        self.num_classes = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.kws_destroy(self._h)
+            self._h = _c_ctx()
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, error_cls=KWSError):
+        if rc != KWS_OK:
+            raise error_cls(f"{self._lib.kws_last_error(self._h).decode()} (code {rc})")
+
+    def use_torch_stream(self):
+        """Enqueue on torch's current stream for this device, so torch sees the work in order."""
+        import torch
+
+        self._check(self._lib.kws_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def use_own_stream(self):
+        self._check(self._lib.kws_set_stream(self._h, None))
+
+    def sync(self):
+        self._check(self._lib.kws_sync(self._h))
+
+    # -- front end ------------------------------------------------------------------------------
+    def set_frontend(self, sample_rate=16000, n_samples=16000, frame_len=400, frame_step=160, nfft=512, nfilt=26,
+                     numcep=10, preemph=0.97, ceplifter=22):
+        self._check(
+            self._lib.kws_set_frontend(self._h, sample_rate, n_samples, frame_len, frame_step, nfft, nfilt, numcep,
+                                       float(preemph), ceplifter),
+            AudioProcessingError,
+        )
+
+    def frontend_shape(self):
+        nf, nc = C.c_int(), C.c_int()
+        self._check(self._lib.kws_frontend_shape(self._h, C.byref(nf), C.byref(nc)), AudioProcessingError)
+        return nf.value, nc.value
+
+    def mfcc_i16(self, wav, out):
+        self._check(self._lib.kws_mfcc_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(out)), AudioProcessingError)
+
+    def mfcc_f32(self, wav, out):
+        self._check(self._lib.kws_mfcc_f32(self._h, _ptr(wav), int(wav.shape[0]), _ptr(out)), AudioProcessingError)
+
+    # -- model ----------------------------------------------------------------------------------
+    def load_dscnn(self, blob: np.ndarray, num_classes: int):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(
+            self._lib.kws_load_dscnn(self._h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, int(num_classes)),
+            ModelError,
+        )
+        self.num_classes = int(num_classes)
+
+    def forward_f32(self, feat, logits, label=None):
+        self._check(
+            self._lib.kws_forward_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
+            ModelError,
+        )
+
+    def forward_debug_f32(self, feat, logits, label, act, use_mfma=True):
+        self._check(
+            self._lib.kws_forward_debug_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits),
+                                            _ptr(label) if label is not None else None,
+                                            _ptr(act) if act is not None else None, 1 if use_mfma else 0),
+            ModelError,
+        )
+
+    def infer_i16(self, wav, logits, label=None):
+        self._check(
+            self._lib.kws_infer_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
+            ModelError,
+        )
+
+    def reserve(self, max_batch: int):
+        self._check(self._lib.kws_reserve(self._h, int(max_batch)))
+
+    # -- sigproc operators ----------------------------------------------------------------------
+    def preemphasis_f32(self, sig, coeff, out):
+        self._check(self._lib.kws_preemphasis_f32(self._h, _ptr(sig), int(sig.numel()), float(coeff), _ptr(out)), AudioProcessingError)
+
+    def framesig_f32(self, sig, frame_len, frame_step, window, frames):
+        self._check(
+            self._lib.kws_framesig_f32(self._h, _ptr(sig), int(sig.numel()), int(frame_len), int(frame_step),
+                                       _ptr(window) if window is not None else None, _ptr(frames)),
+            AudioProcessingError,
+        )
+
+    def spec512_f32(self, frames, power, spec):
+        self._check(
+            self._lib.kws_spec512_f32(self._h, _ptr(frames), int(frames.shape[0]), int(frames.shape[1]), 1 if power else 0, _ptr(spec)),
+            AudioProcessingError,
+        )
+
+    # -- measurement ----------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self._lib.kws_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._check(self._lib.kws_prof_reset(self._h))
+
+    def prof_read(self, kernel_id: int):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self._lib.kws_prof_read(self._h, int(kernel_id), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def kernel_name(kernel_id: int) -> str:
+    return lib().kws_kernel_name(int(kernel_id)).decode()
+
+
+# -- host-only helpers (no GPU) --------------------------------------------------------------------
+def host_mel_edges(nfilt=26, nfft=512, sample_rate=16000) -> np.ndarray:
+    out = (C.c_int * (nfilt + 2))()
+    rc = lib().kws_host_mel_edges(nfilt, nfft, sample_rate, out)
+    if rc != KWS_OK:
+        raise KWSError(f"kws_host_mel_edges failed ({rc})")
+    return np.array(out[:], dtype=np.int64)
+
+
+def host_mel_dense(nfilt=26, nfft=512, sample_rate=16000) -> np.ndarray:
+    out = np.zeros((nfilt, nfft // 2 + 1), np.float32)
+    rc = lib().kws_host_mel_dense(nfilt, nfft, sample_rate, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != KWS_OK:
+        raise KWSError(f"kws_host_mel_dense failed ({rc})")
+    return out
+
+
+def host_dct_lifter(nfilt=26, numcep=10, ceplifter=22) -> np.ndarray:
+    out = np.zeros((numcep, nfilt), np.float32)
+    rc = lib().kws_host_dct_lifter(nfilt, numcep, ceplifter, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != KWS_OK:
+        raise KWSError(f"kws_host_dct_lifter failed ({rc})")
+    return out
+
+
+_contexts: dict = {}
+
+
+def default_context(device: int = 0) -> Context:
+    """Process-wide context per GPU, bound to torch's current stream at each use by the callers."""
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx

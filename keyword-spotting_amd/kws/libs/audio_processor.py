@@ -1,0 +1,228 @@
+"""Feature extraction for keyword spotting on MI355X.
+
+Drop-in for the reference's ``kws/libs/audio_processor.py``: same ``AudioConfig`` fields and defaults
+(``:20-72``), same ``AudioProcessor(dataset_path, config)`` with ``transform(filepath, label)``
+(``:130-170``) and ``extract_features(signal, ...)`` (``:235-278``).  The MFCC arithmetic the reference
+delegates to ``python_speech_features.mfcc`` runs in the batched HIP kernel behind ``kws_mfcc_i16`` /
+``kws_mfcc_f32`` (include/kws_hip.h).  WAV decoding and the random augmentations stay on the host.
+
+Additions for batched use: ``extract_features_batch`` (device tensor in, ``float32[B,1,T,F]`` out --
+the collated batch of the reference's data loader) and ``load_pcm16``.
+"""
+from __future__ import annotations
+
+import random
+import wave
+from dataclasses import asdict, dataclass
+from decimal import ROUND_HALF_UP, Decimal
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from kws.common.errors import AudioProcessingError, handle_error
+
+BACKGROUND_NOISE_DIR = "_background_noise_"
+SILENCE_INDEX = 0
+
+
+@dataclass
+class AudioConfig:
+    """Audio / feature parameters (defaults = reference ``AudioConfig``)."""
+
+    # background noise mixing
+    background_volume: float = 0.1
+    background_frequency: float = 0.8
+    use_background_noise: bool = True
+    # clip geometry
+    sample_rate: int = 16000
+    clip_duration_ms: int = 1000
+    time_shift_ms: float = 100
+    # MFCC
+    frame_length: float = 0.025
+    frame_step: float = 0.01
+    num_cepstral_coeffs: int = 10
+    num_mel_filters: int = 26
+    fft_size: int = 512
+
+    @property
+    def time_shift(self) -> int:
+        return int((self.time_shift_ms * self.sample_rate) / 1000)
+
+    @property
+    def desired_samples(self) -> int:
+        return int(self.sample_rate * self.clip_duration_ms / 1000)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict(self)
+
+
+def _half_up(x: float) -> int:
+    return int(Decimal(x).quantize(Decimal("1"), rounding=ROUND_HALF_UP))
+
+
+def load_pcm16(path, sample_rate: int = 16000) -> np.ndarray:
+    """Read a mono 16-bit PCM WAV as int16 (what ``librosa.load`` scales by 1/32768 in the reference,
+    ``audio_processor.py:145``).  Stereo is averaged like librosa's mono mix-down; a different sample
+    rate is refused (librosa would resample with soxr, which cannot be reproduced bit for bit here)."""
+    with wave.open(str(path), "rb") as w:
+        if w.getsampwidth() != 2:
+            raise AudioProcessingError(f"{path}: only 16-bit PCM WAV is supported (sample width {w.getsampwidth()})")
+        if w.getframerate() != sample_rate:
+            raise AudioProcessingError(f"{path}: sample rate {w.getframerate()} != {sample_rate}; resampling is not implemented")
+        data = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+        ch = w.getnchannels()
+    if ch > 1:
+        data = data.reshape(-1, ch)
+        return data  # caller mixes down in float
+    return data
+
+
+def _to_float_mono(pcm: np.ndarray) -> np.ndarray:
+    x = pcm.astype(np.float32) / np.float32(32768.0)
+    return x.mean(axis=1, dtype=np.float32) if x.ndim == 2 else x
+
+
+def fix_length(x: np.ndarray, size: int) -> np.ndarray:
+    """Trim or zero-pad the last axis to ``size`` (``librosa.util.fix_length``, ``audio_processor.py:148``)."""
+    n = x.shape[-1]
+    if n >= size:
+        return x[..., :size]
+    return np.concatenate([x, np.zeros(x.shape[:-1] + (size - n,), dtype=x.dtype)], axis=-1)
+
+
+class AudioProcessor:
+    """WAV -> fixed length -> (augment) -> MFCC, with the MFCC on the GPU."""
+
+    def __init__(self, dataset_path: Optional[Path], config: Optional[AudioConfig] = None, device: int = 0):
+        self.config = config if config is not None else AudioConfig()
+        self.dataset_path = Path(dataset_path) if dataset_path is not None else None
+        self.device = device
+        self._ctx = None
+        self._ctx_key = None
+        try:
+            self.background_data = self._load_background_data()
+        except Exception as e:  # same wrapping as the reference (:96-101)
+            handle_error(e, AudioProcessingError, "Failed to initialize audio processor")
+
+    # ------------------------------------------------------------------ host side
+    def _load_background_data(self) -> List[np.ndarray]:
+        if self.dataset_path is None:
+            return []
+        folder = self.dataset_path / BACKGROUND_NOISE_DIR
+        if not folder.exists():
+            return []
+        clips = []
+        for wav_path in sorted(folder.glob("*.wav")):
+            try:
+                clips.append(_to_float_mono(load_pcm16(wav_path, self.config.sample_rate)))
+            except Exception:
+                continue  # unreadable background files are skipped, as in the reference (:119-123)
+        return clips
+
+    def _apply_time_shift(self, audio: np.ndarray) -> np.ndarray:
+        """Random shift by up to +-time_shift samples, zero filled (``:172-188``)."""
+        limit = self.config.time_shift
+        amount = np.random.randint(-limit, limit) if limit > 0 else 0
+        n = self.config.desired_samples
+        out = np.zeros(n, dtype=audio.dtype)
+        if amount >= 0:
+            out[amount:] = audio[: n - amount]
+        else:
+            out[: n + amount] = audio[-amount:n]
+        return out
+
+    def _add_background_noise(self, audio: np.ndarray, label: int, background_data: List[np.ndarray]) -> np.ndarray:
+        """Mix a random background segment at a random volume (``:190-233``)."""
+        if not background_data:
+            return audio
+        n = self.config.desired_samples
+        bg = random.choice(background_data)
+        if len(bg) <= n:
+            bg = np.tile(bg, int(np.ceil(n / len(bg))) + 1)
+        start = np.random.randint(0, len(bg) - n)
+        if label == SILENCE_INDEX:
+            volume = np.random.uniform(0, 1)
+        elif np.random.uniform(0, 1) < self.config.background_frequency:
+            volume = np.random.uniform(0, self.config.background_volume)
+        else:
+            volume = 0
+        return audio + bg[start:start + n] * volume
+
+    def transform(self, filepath: str, label: int) -> np.ndarray:
+        """One file -> MFCC ``[frames, numcep]`` with the reference's augmentation order (``:130-170``)."""
+        try:
+            audio = _to_float_mono(load_pcm16(filepath, self.config.sample_rate))
+            audio = fix_length(audio, self.config.desired_samples)
+            if label == SILENCE_INDEX:
+                audio = np.zeros_like(audio)
+            audio = self._apply_time_shift(audio)
+            if self.config.use_background_noise or label == SILENCE_INDEX:
+                audio = self._add_background_noise(audio, label, self.background_data)
+            return self.extract_features(audio, winlen=self.config.frame_length, winstep=self.config.frame_step)
+        except Exception as e:
+            raise AudioProcessingError(f"Error processing audio file {filepath}: {str(e)}") from e
+
+    # ------------------------------------------------------------------ device side
+    def _context(self, n_samples: int, samplerate: int, numcep: int, winlen: float, winstep: float, nfilt: int):
+        from kws import _native
+
+        nfft = max(self.config.fft_size, int(winlen * samplerate))  # the reference overrides its nfft argument (:268)
+        key = (n_samples, samplerate, numcep, nfft, _half_up(winlen * samplerate), _half_up(winstep * samplerate), nfilt)
+        if self._ctx is None:
+            self._ctx = _native.Context(self.device, AudioProcessingError)
+        if key != self._ctx_key:
+            self._ctx.set_frontend(sample_rate=samplerate, n_samples=n_samples, frame_len=key[4], frame_step=key[5],
+                                   nfft=nfft, nfilt=nfilt, numcep=numcep, preemph=0.97, ceplifter=22)
+            self._ctx_key = key
+        return self._ctx
+
+    def extract_features(self, signal: np.ndarray, samplerate: int = None, numcep: int = None, nfft: int = None,
+                         winlen: float = None, winstep: float = None, nfilt: int = None) -> np.ndarray:
+        """MFCC of one clip: float signal in [-1, 1] (or int16 PCM) -> ``float64[frames, numcep]``.
+
+        Falsy arguments fall back to the config exactly as in the reference (``:260-268``); ``nfft`` is
+        accepted and ignored there too.  Values are computed in float32 on the GPU and returned as
+        float64 to keep the reference's dtype."""
+        import torch
+
+        c = self.config
+        samplerate = samplerate or c.sample_rate
+        numcep = numcep or c.num_cepstral_coeffs
+        winlen = winlen or c.frame_length
+        winstep = winstep or c.frame_step
+        nfilt = nfilt or c.num_mel_filters
+        sig = np.asarray(signal)
+        if sig.ndim != 1:
+            raise AudioProcessingError("extract_features expects a 1-D signal (use extract_features_batch for batches)")
+        ctx = self._context(sig.shape[0], samplerate, numcep, winlen, winstep, nfilt)
+        dev = torch.device("cuda", self.device)
+        if sig.dtype == np.int16:
+            x = torch.from_numpy(np.ascontiguousarray(sig)).to(dev)[None]
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float32)).to(dev)[None]
+        return self.extract_features_batch(x, _ctx=ctx)[0, 0].double().cpu().numpy()
+
+    def extract_features_batch(self, signals, _ctx=None):
+        """``int16[B,n]`` (PCM) or ``float32[B,n]`` device tensor -> ``float32[B,1,frames,numcep]`` device tensor:
+        the batch the reference builds with ``__getitem__`` + default collate (``kws/libs/data_loader.py:96-105``)."""
+        import torch
+
+        if not signals.is_cuda:
+            raise AudioProcessingError("extract_features_batch needs a CUDA/ROCm tensor (there is no CPU path)")
+        if signals.dim() != 2:
+            raise AudioProcessingError("extract_features_batch expects [B, n_samples]")
+        c = self.config
+        ctx = _ctx or self._context(signals.shape[1], c.sample_rate, c.num_cepstral_coeffs, c.frame_length, c.frame_step,
+                                    c.num_mel_filters)
+        frames, numcep = ctx.frontend_shape()
+        signals = signals.contiguous()
+        out = torch.empty((signals.shape[0], 1, frames, numcep), dtype=torch.float32, device=signals.device)
+        ctx.use_torch_stream()
+        if signals.dtype == torch.int16:
+            ctx.mfcc_i16(signals, out)
+        elif signals.dtype == torch.float32:
+            ctx.mfcc_f32(signals, out)
+        else:
+            raise AudioProcessingError(f"unsupported signal dtype {signals.dtype}: use int16 PCM or float32")
+        return out

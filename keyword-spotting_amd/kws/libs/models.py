@@ -1,0 +1,143 @@
+"""Keyword-spotting models whose forward runs in the fused gfx950 kernel.
+
+Drop-in for the reference's ``kws/libs/models.py``: ``KeywordSpottingModel`` (``forward`` / ``save`` /
+``load``, ``:13-72``), ``DepthwiseSeparableConvBlock`` (``:75-119``) and
+``DepthwiseSeparableConv(num_classes=12, input_channels=1)`` (``:122-183``) with identical parameter
+names, shapes and initialisation, so reference checkpoints (bare ``state_dict`` or the trainer's
+``{"model_state_dict": ...}``) load unchanged.  The modules only *hold* parameters; the arithmetic of
+``forward`` is ``kws_forward_f32`` (include/kws_hip.h): LDS-resident activations, depthwise 3x3 on the
+VALU, pointwise 1x1 and conv1 on the f32 matrix cores.  Inference only -- no autograd graph is built.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from kws.common.errors import ModelError
+
+FEATURE_SHAPE = (1, 99, 10)  # [C, T, F] the fused kernel is built for (reference defaults)
+
+
+class KeywordSpottingModel(nn.Module, abc.ABC):
+    """Interface every KWS model implements."""
+
+    def __init__(self, num_classes: int, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+
+    @abc.abstractmethod
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """``x [B,1,T,F]`` -> logits ``[B,num_classes]``."""
+
+    def save(self, path: str) -> None:
+        try:
+            torch.save(self.state_dict(), path)
+        except Exception as e:
+            raise ModelError(f"Failed to save model to {path}: {str(e)}") from e
+
+    def load(self, path: str, device: Optional[torch.device] = None) -> None:
+        try:
+            if device is None:
+                device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+            state = torch.load(path, map_location=device, weights_only=True)
+            if isinstance(state, dict) and "model_state_dict" in state:  # trainer checkpoints (training.py:199-216)
+                state = state["model_state_dict"]
+            self.load_state_dict(state)
+            self.to(device)
+        except Exception as e:
+            raise ModelError(f"Failed to load model from {path}: {str(e)}") from e
+
+
+class DepthwiseSeparableConvBlock(nn.Module):
+    """Parameter holder for one block: 3x3 depthwise + 1x1 pointwise (the pointwise keeps the
+    reference's ``padding=padding`` -- the relu(bias) ring -- which the fused kernel reproduces)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, padding: int = 1):
+        super().__init__()
+        self.depthwise = nn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                                   groups=in_channels)
+        self.pointwise = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=padding)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise ModelError("a DepthwiseSeparableConvBlock has no standalone kernel: blocks run fused inside "
+                         "DepthwiseSeparableConv.forward (kws_forward_f32)")
+
+
+class DepthwiseSeparableConv(KeywordSpottingModel):
+    """DS-CNN: conv1 (1->64, 10x10, s2, p2) + 4 depthwise-separable blocks + global pool + Linear."""
+
+    def __init__(self, num_classes: int = 12, input_channels: int = 1):
+        super().__init__(num_classes)
+        if input_channels != 1:
+            raise ModelError("the fused kernel is built for input_channels=1 (mono MFCC map)")
+        self.conv1 = nn.Conv2d(input_channels, 64, kernel_size=10, stride=2, padding=2)
+        self.dsconv1 = DepthwiseSeparableConvBlock(64, 64)
+        self.dsconv2 = DepthwiseSeparableConvBlock(64, 64)
+        self.dsconv3 = DepthwiseSeparableConvBlock(64, 64)
+        self.dsconv4 = DepthwiseSeparableConvBlock(64, 64)
+        self.fc = nn.Linear(64, num_classes)
+        self._initialize_weights()
+        self._ctx = None
+        self._uploaded = None  # fingerprint of the parameters currently on the device
+
+    def _initialize_weights(self):
+        # same scheme as the reference (:149-158)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ device plumbing
+    def packed_weights(self) -> np.ndarray:
+        """The 20 ``state_dict`` tensors, in order, as one float32 vector (``kws_load_dscnn`` layout)."""
+        return np.concatenate([v.detach().to("cpu", torch.float32).reshape(-1).numpy() for v in self.state_dict().values()])
+
+    def _context(self, device_index: int):
+        from kws import _native
+
+        if self._ctx is None or self._ctx.device != device_index:
+            self._ctx = _native.Context(device_index, ModelError)
+            self._uploaded = None
+        fp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if fp != self._uploaded:
+            self._ctx.load_dscnn(self.packed_weights(), self.num_classes)
+            self._uploaded = fp
+        self._ctx.use_torch_stream()
+        return self._ctx
+
+    def _check_input(self, x: torch.Tensor, what: str):
+        if not x.is_cuda:
+            raise ModelError(f"{what} needs a CUDA/ROCm tensor: the forward is a HIP kernel and has no CPU fallback")
+
+    def forward(self, x: torch.Tensor, return_labels: bool = False):
+        """``float32[B,1,99,10]`` on the GPU -> logits ``float32[B,num_classes]`` (and argmax labels)."""
+        self._check_input(x, "DepthwiseSeparableConv.forward")
+        if x.dim() != 4 or tuple(x.shape[1:]) != FEATURE_SHAPE:
+            raise ModelError(f"expected input [B,1,99,10], got {tuple(x.shape)}")
+        ctx = self._context(x.device.index or 0)
+        x = x.detach().to(torch.float32).contiguous()
+        logits = torch.empty((x.shape[0], self.num_classes), dtype=torch.float32, device=x.device)
+        labels = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
+        ctx.forward_f32(x, logits, labels)
+        return (logits, labels) if return_labels else logits
+
+    def infer_pcm16(self, wav: torch.Tensor):
+        """Fused path: ``int16[B,16000]`` PCM on the GPU -> (logits, labels); MFCC + DS-CNN back to back
+        on one stream, features never leave the device (``kws_infer_i16``)."""
+        self._check_input(wav, "DepthwiseSeparableConv.infer_pcm16")
+        if wav.dtype != torch.int16 or wav.dim() != 2:
+            raise ModelError("infer_pcm16 expects an int16 tensor [B, n_samples]")
+        ctx = self._context(wav.device.index or 0)
+        wav = wav.contiguous()
+        logits = torch.empty((wav.shape[0], self.num_classes), dtype=torch.float32, device=wav.device)
+        labels = torch.empty((wav.shape[0],), dtype=torch.int32, device=wav.device)
+        ctx.infer_i16(wav, logits, labels)
+        return logits, labels

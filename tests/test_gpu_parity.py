@@ -1,0 +1,347 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle.
+
+Tolerances (BASELINE.json north_star): logits within 1e-4 of the CPU reference path, argmax labels
+identical; MFCC within 1e-4 (float32 kernel vs float64 psf arithmetic); integer/bit-level pieces
+(PCM scaling + pre-emphasis, labels, run-to-run determinism) exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_clips
+from oracle import dscnn as o_dscnn
+from oracle import psf_mfcc as o_mfcc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def native():
+    from kws import _native
+
+    return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(native):
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def state_from_blob(blob):
+    st, off = {}, 0
+    for k, shp in o_dscnn.state_shapes(12).items():
+        n = int(np.prod(shp))
+        st[k] = torch.from_numpy(blob[off:off + n].reshape(shp).copy())
+        off += n
+    return st
+
+
+def gpu_mfcc(ctx, dev, clips):
+    wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
+    nf, nc = ctx.frontend_shape()
+    out = torch.empty((len(clips), 1, nf, nc), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(wav, out)
+    ctx.sync()
+    return out.cpu().numpy()
+
+
+def gpu_infer(ctx, dev, clips):
+    wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
+    logits = torch.empty((len(clips), 12), dtype=torch.float32, device=dev)
+    labels = torch.empty((len(clips),), dtype=torch.int32, device=dev)
+    ctx.infer_i16(wav, logits, labels)
+    ctx.sync()
+    return logits.cpu().numpy(), labels.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------- MFCC
+def test_mfcc_golden_clips(ctx, dev, sigproc_golden):
+    clips = sigproc_golden["clips"]
+    got = gpu_mfcc(ctx, dev, clips)
+    want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
+    assert got.shape == (len(clips), 1, 99, 10) and got.dtype == np.float32
+    err = np.abs(got[:, 0] - want).max(axis=(1, 2))
+    for name, e in zip(sigproc_golden["names"], err):
+        assert e <= TOL, f"{name}: MFCC max abs err {e}"
+    # all-zero clip: c0 = log(eps) to float32 rounding, every other coefficient exactly 0
+    assert np.all(np.abs(got[0, 0, :, 0] - (-36.04365338911715)) < 1e-5)
+    assert np.all(got[0, 0, :, 1:] == 0.0)
+
+
+@pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
+def test_mfcc_random_batch(ctx, dev, kind, seed):
+    clips = synth_clips(96, seed, kind)
+    got = gpu_mfcc(ctx, dev, clips)[:, 0]
+    want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_mfcc_f32_entry_equals_i16_entry(ctx, dev):
+    clips = synth_clips(5, 3)
+    a = gpu_mfcc(ctx, dev, clips)
+    x = torch.from_numpy(o_mfcc.pcm16_to_float(clips)).to(dev)
+    out = torch.empty((5, 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_f32(x, out)
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), a)
+
+
+def test_mfcc_unaligned_pointer_takes_scalar_path(ctx, dev):
+    clips = synth_clips(3, 4)
+    ref = gpu_mfcc(ctx, dev, clips)
+    buf = torch.zeros(3 * 16000 + 1, dtype=torch.int16, device=dev)
+    view = buf[1:].view(3, 16000)
+    view.copy_(torch.from_numpy(clips))
+    out = torch.empty((3, 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(view, out)
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_mfcc_other_geometry(native, dev):
+    """Half-second clips, 13 cepstra, 40 filters, 8 kHz: exercises the table builder and ragged tail."""
+    c = native.Context(0)
+    try:
+        spec = o_mfcc.FrontendSpec(sample_rate=8000, n_samples=4000, winlen=0.032, winstep=0.012, nfft=512, nfilt=40, numcep=13)
+        c.set_frontend(sample_rate=8000, n_samples=4000, frame_len=spec.frame_len, frame_step=spec.frame_step,
+                       nfft=512, nfilt=40, numcep=13)
+        assert c.frontend_shape() == (spec.num_frames, 13)
+        clips = np.random.default_rng(9).integers(-20000, 20000, size=(7, 4000), dtype=np.int16)
+        got = gpu_mfcc(c, dev, clips)[:, 0]
+        want = np.stack([o_mfcc.mfcc(o_mfcc.pcm16_to_float(x), spec) for x in clips])
+        assert np.abs(got - want).max() <= TOL
+    finally:
+        c.close()
+
+
+def test_frontend_rejects_unsupported(native):
+    from kws.common.errors import AudioProcessingError
+
+    c = native.Context(0)
+    try:
+        with pytest.raises(AudioProcessingError):
+            c.set_frontend(nfft=1024)
+        with pytest.raises(AudioProcessingError):
+            c.set_frontend(frame_len=600)
+        assert c.frontend_shape() == (99, 10)  # a refused configuration leaves the previous one intact
+    finally:
+        c.close()
+
+
+# ------------------------------------------------------------------------------------------- sigproc operators
+def test_sigproc_operators_against_reference_golden(ctx, dev, sigproc_golden):
+    from kws.libs.speech_features import sigproc
+
+    g = sigproc_golden
+    keep = g["keep_frames"]
+    for clip, head, ps_ref in zip(g["clips"], g["preemph_head_f32"], g["powspec_f64"]):
+        x = torch.from_numpy(o_mfcc.pcm16_to_float(clip)).to(dev)
+        y = sigproc.preemphasis(x, 0.97)
+        assert np.array_equal(y[:64].cpu().numpy(), head)  # float32 pre-emphasis is bit-exact
+        frames = sigproc.framesig(y, 400, 160, winfunc=lambda n, device=None: torch.ones(n, device=device))
+        assert tuple(frames.shape) == (99, 400)
+        assert torch.equal(frames[1], y[160:560]) and float(frames[98, 320:].abs().max()) == 0.0
+        ps = sigproc.powspec(frames, 512).cpu().numpy().astype(np.float64)
+        scale = max(ps_ref.max(), 1e-30)
+        assert np.abs(ps[keep] - ps_ref).max() <= 2e-6 * scale
+        mag = sigproc.magspec(frames, 512).cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(mag[keep] ** 2 / 512, ps_ref, atol=4e-6 * scale)
+
+
+def test_sigproc_reference_unit_test_recipe(dev, sigproc_golden):
+    """The reference's own test (tests/kws/libs/speech_features/test_sigproc.py:8-21) with the rectangular
+    window, at float32 precision: rand(16000) -> framesig(400,160) -> magspec(512)."""
+    from kws.libs.speech_features import sigproc
+
+    np.random.seed(0)
+    sig = torch.from_numpy(np.random.rand(16000)).to(dev)  # float64 in, float64 out, float32 inside
+    frames = sigproc.framesig(sig, 400, 160, winfunc=lambda n, device=None: torch.ones(n, device=device))
+    mag = sigproc.magspec(frames, 512)
+    assert mag.dtype == torch.float64
+    ref = sigproc_golden["reftest_magspec_f64"]
+    np.testing.assert_allclose(mag.cpu().numpy()[sigproc_golden["keep_frames"]], ref, rtol=1e-5, atol=2e-4)
+    hann = sigproc.framesig(sig.float(), 400, 160)  # default window is Hann, as in the reference signature
+    want = sig.float()[:400] * torch.hann_window(400, device=dev)
+    assert torch.allclose(hann[0], want, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- DS-CNN
+def split_act(act):
+    sizes = [("conv1", 141), ("dsconv1", 141), ("dsconv2", 245), ("dsconv3", 357)]
+    out, off = {}, 0
+    for name, p in sizes:
+        out[name] = act[:, off:off + 64 * p].reshape(-1, 64, p)
+        off += 64 * p
+    out["pool"] = act[:, off:off + 64]
+    return out
+
+
+@pytest.mark.parametrize("tag", ["n01", "default"])
+@pytest.mark.parametrize("use_mfma", [False, True])
+def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, tag, use_mfma):
+    g = dscnn_golden
+    blob = g[f"{tag}.blob"]
+    ctx.load_dscnn(blob, 12)
+    x = torch.from_numpy(g["x"]).to(dev)
+    B = x.shape[0]
+    logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
+    labels = torch.empty((B,), dtype=torch.int32, device=dev)
+    act = torch.zeros((B, native.ACT_FLOATS_PER_CLIP), dtype=torch.float32, device=dev)
+    ctx.forward_debug_f32(x, logits, labels, act, use_mfma=use_mfma)
+    ctx.sync()
+    _, layers = o_dscnn.forward(state_from_blob(blob), torch.from_numpy(g["x"]), return_layers=True)
+    got = split_act(act.cpu().numpy())
+    want = {
+        "conv1": layers["conv1"].numpy().reshape(B, 64, -1),
+        "dsconv1": layers["dsconv1"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
+        "dsconv2": layers["dsconv2"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
+        "dsconv3": layers["dsconv3"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
+        "pool": layers["pool"].numpy(),
+    }
+    for name in ["conv1", "dsconv1", "dsconv2", "dsconv3", "pool"]:
+        scale = max(1.0, float(np.abs(want[name]).max()))
+        err = float(np.abs(got[name] - want[name]).max())
+        assert err <= 2e-5 * scale, f"{tag} mfma={use_mfma} layer {name}: max abs err {err} (scale {scale})"
+    # against the reference module's own logits (golden), and its labels
+    assert np.abs(logits.cpu().numpy() - g[f"{tag}.logits"]).max() <= TOL
+    if tag == "n01":
+        assert np.array_equal(labels.cpu().numpy(), g[f"{tag}.label"])
+
+
+def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
+    g = dscnn_golden
+    ctx.load_dscnn(g["n01.blob"], 12)
+    x = torch.from_numpy(g["x"]).to(dev)
+    a = torch.empty((x.shape[0], 12), dtype=torch.float32, device=dev)
+    la = torch.empty((x.shape[0],), dtype=torch.int32, device=dev)
+    ctx.forward_f32(x, a, la)
+    b = torch.empty_like(a)
+    ctx.forward_f32(x, b, None)  # label pointer may be NULL
+    ctx.sync()
+    assert torch.equal(a, b)
+    assert np.array_equal(la.cpu().numpy(), g["n01.label"])
+
+
+# ------------------------------------------------------------------------------------------- fused wav -> label
+@pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
+def test_infer_matches_oracle(ctx, dev, kind, seed):
+    state = o_dscnn.random_state(seed=1, std=0.1)
+    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+    clips = synth_clips(160, seed, kind)
+    logits, labels = gpu_infer(ctx, dev, clips)
+    want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips)))
+    err = np.abs(logits - want.numpy()).max()
+    assert err <= TOL, f"logits max abs err {err}"
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()  # a tie inside the tolerance may legitimately flip
+    assert np.array_equal(labels[clear], o_dscnn.predict(want).numpy()[clear])
+    assert clear.mean() > 0.95
+
+
+def test_infer_requires_model(native, dev):
+    from kws.common.errors import ModelError
+
+    c = native.Context(0)
+    try:
+        wav = torch.zeros((2, 16000), dtype=torch.int16, device=dev)
+        logits = torch.empty((2, 12), dtype=torch.float32, device=dev)
+        with pytest.raises(ModelError):
+            c.infer_i16(wav, logits, None)
+        with pytest.raises(ModelError):
+            c.load_dscnn(np.zeros(100, np.float32), 12)  # wrong blob size
+    finally:
+        c.close()
+
+
+def test_full_batch_properties(ctx, dev):
+    """BASELINE workload size (B = 4096): properties that need no oracle at that size."""
+    state = o_dscnn.random_state(seed=1, std=0.1)
+    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+    B = 4096
+    clips = synth_clips(B, 0, "uniform")
+    clips[5] = 0
+    clips[777] = 0
+    logits, labels = gpu_infer(ctx, dev, clips)
+    assert np.isfinite(logits).all() and labels.min() >= 0 and labels.max() < 12
+    # argmax consistency (first maximum wins) on the device's own logits
+    assert np.array_equal(labels, np.argmax(logits, axis=1).astype(np.int32))
+    # determinism: bit-identical on a second run
+    logits2, labels2 = gpu_infer(ctx, dev, clips)
+    assert np.array_equal(logits, logits2) and np.array_equal(labels, labels2)
+    # clips are independent: a sub-batch and a permutation give bit-identical rows
+    sub = [0, 5, 4095, 1234, 777, 31]
+    ls, _ = gpu_infer(ctx, dev, clips[sub])
+    assert np.array_equal(ls, logits[sub])
+    perm = np.random.default_rng(1).permutation(B)
+    lp, _ = gpu_infer(ctx, dev, clips[perm])
+    assert np.array_equal(lp, logits[perm])
+    # identical inputs -> identical outputs; a sample of the batch against the oracle
+    assert np.array_equal(logits[5], logits[777])
+    pick = np.arange(0, B, 64)
+    want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips[pick]))).numpy()
+    assert np.abs(logits[pick] - want).max() <= TOL
+
+
+def test_batch_of_one_and_ragged_sizes(ctx, dev):
+    state = o_dscnn.random_state(seed=1, std=0.1)
+    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+    clips = synth_clips(67, 5)
+    full, _ = gpu_infer(ctx, dev, clips)
+    for n in (1, 2, 63, 67):
+        part, _ = gpu_infer(ctx, dev, clips[:n])
+        assert np.array_equal(part, full[:n])
+
+
+# ------------------------------------------------------------------------------------------- host mirror of the reference API
+def test_python_surface_end_to_end(dev, tmp_path):
+    import wave
+
+    from kws.inference import KeywordSpotter
+    from kws.libs.audio_processor import AudioConfig, AudioProcessor
+    from kws.libs.models import DepthwiseSeparableConv
+
+    clips = synth_clips(4, 6, "gauss")
+    clips[0] = synth_clips(1, 7)[0]
+    # AudioProcessor.extract_features: float signal in [-1,1] -> float64 [99,10]
+    ap = AudioProcessor(None, AudioConfig())
+    feat = ap.extract_features(o_mfcc.pcm16_to_float(clips[1]))
+    assert feat.shape == (99, 10) and feat.dtype == np.float64
+    assert np.abs(feat - o_mfcc.extract_features_pcm16(clips[1])).max() <= TOL
+    batch = ap.extract_features_batch(torch.from_numpy(clips).to(dev))
+    assert tuple(batch.shape) == (4, 1, 99, 10) and batch.dtype == torch.float32
+    # model with the reference's state_dict layout
+    torch.manual_seed(3)
+    model = DepthwiseSeparableConv(num_classes=12)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    logits = model(batch)
+    want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips)))
+    assert float((logits.cpu() - want).abs().max()) <= TOL
+    # save / load round trip, then wav files -> words
+    path = tmp_path / "model.pth"
+    model.save(str(path))
+    spotter = KeywordSpotter()
+    spotter.load_weights(str(path))
+    files = []
+    for i, c in enumerate(clips):
+        f = tmp_path / f"clip{i}.wav"
+        with wave.open(str(f), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(c[: 16000 - 100 * i].tobytes())  # shorter files are zero-padded to one second
+        files.append(str(f))
+    got = spotter.infer_files(files)
+    padded = np.stack([np.concatenate([c[: 16000 - 100 * i], np.zeros(100 * i, np.int16)]) for i, c in enumerate(clips)])
+    want2 = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(padded)))
+    assert [g[0] for g in got] == o_dscnn.predict(want2).tolist()
+    assert all(word == spotter.words[idx] for idx, word in got)

@@ -1,0 +1,41 @@
+"""N>1 path on CPU: world_size-2 gloo run of the bench's sharding + timing harness."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import bench
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_bounds_partition():
+    for total in (1, 7, 8, 4096, 8192, 10):
+        for world in (1, 2, 3, 4, 8):
+            spans = [bench.shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert bench.shard_bounds(8192, 8, 3) == (3072, 4096)  # BASELINE config 4: 8 x 1024
+
+
+def test_two_rank_gloo_run():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(HERE, "_dist_worker.py")]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ok"] and out["world"] == 2 and out["shards"] == [[0, 5], [5, 10]]
+
+
+def test_weights_and_clips_are_seeded():
+    import numpy as np
+
+    assert bench.synth_weights().shape == (26444,)
+    assert np.array_equal(bench.synth_clips(3, 5), bench.synth_clips(3, 5))
+    assert bench.synth_clips(2, 0).dtype == np.int16
