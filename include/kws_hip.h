@@ -52,9 +52,10 @@ int kws_abi_version(void);
 int kws_create(kws_ctx** out, int device_id);
 void kws_destroy(kws_ctx* ctx);
 
-/* Enqueue on the caller's stream instead (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
- * NULL returns to the context's own stream. */
-int kws_set_stream(kws_ctx* ctx, void* hip_stream);
+/* external != 0: enqueue on the caller's stream `hip_stream` (a hipStream_t, e.g.
+ * torch.cuda.current_stream().cuda_stream; NULL is the device's default stream, which is what torch
+ * uses unless told otherwise).  external == 0: return to the context's own stream. */
+int kws_set_stream(kws_ctx* ctx, void* hip_stream, int external);
 
 /* Block the host until everything enqueued on the context's stream has finished. */
 int kws_sync(kws_ctx* ctx);

@@ -242,9 +242,9 @@ void kws_destroy(kws_ctx* c) {
     delete c;
 }
 
-int kws_set_stream(kws_ctx* c, void* hip_stream) {
+int kws_set_stream(kws_ctx* c, void* hip_stream, int external) {
     if (!c) return KWS_EINVAL;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
     return KWS_OK;
 }
 

@@ -110,8 +110,11 @@ __device__ __forceinline__ void load_twiddles(const float2* __restrict__ tw, int
 
 // Write Z to LDS in natural order and return, for the bins this lane owns (k = lane + 64*j, j<4, and
 // k = 256 on lane 0), the power spectra 1/512*|A|^2, 1/512*|B|^2 of the two packed real frames.
-__device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* pbuf, int lane, int power,
-                                            float& ea, float& eb) {
+// nza / nzb: whether frame a / b has any non-zero sample.  An all-zero frame must give exactly 0 (the
+// reference then floors to eps); computed through the packed transform it would instead pick up the
+// partner frame's float32 rounding noise (-140 dB), so it is forced.
+__device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* pbuf, int lane, int power, bool nza,
+                                            bool nzb, float& ea, float& eb) {
     const int k1 = lane >> 3, q = lane & 7;
 #pragma unroll
     for (int d = 0; d < 8; ++d) zbuf[k1 + 8 * q + 64 * d] = v[d];
@@ -132,6 +135,8 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
             pa = sqrtf(pa);
             pb = sqrtf(pb);
         }
+        pa = nza ? pa : 0.f;
+        pb = nzb ? pb : 0.f;
         pbuf[k] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
@@ -222,17 +227,22 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         const float* yb = ya + p.frame_step;
 
         cf v[8];
+        bool nza = false, nzb = false;
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int i = 64 * n1 + lane;
             const bool in = i < p.frame_len;
             v[n1].x = in ? ya[i] : 0.f;
             v[n1].y = (in && has_b) ? yb[i] : 0.f;
+            nza |= v[n1].x != 0.f;
+            nzb |= v[n1].y != 0.f;
         }
+        nza = __any(nza);
+        nzb = __any(nzb);
         fft512(v, xbuf, t1, t2, lane);
 
         float ea, eb;
-        split_power(v, xbuf, pbuf, lane, 1, ea, eb);
+        split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ea, eb);
         ea = wave_sum(ea);
         eb = wave_sum(eb);
 
@@ -338,16 +348,21 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
     const float* ya = frames + (size_t)fa * frame_len;
     const float* yb = ya + frame_len;
     cf v[8];
+    bool nza = false, nzb = false;
 #pragma unroll
     for (int n1 = 0; n1 < 8; ++n1) {
         const int i = 64 * n1 + lane;
         const bool in = i < frame_len;  // frames longer than NFFT are truncated (sigproc.py:65-66)
         v[n1].x = in ? ya[i] : 0.f;
         v[n1].y = (in && has_b) ? yb[i] : 0.f;
+        nza |= v[n1].x != 0.f;
+        nzb |= v[n1].y != 0.f;
     }
+    nza = __any(nza);
+    nzb = __any(nzb);
     fft512(v, xbuf, t1, t2, lane);
     float ea, eb;
-    split_power(v, xbuf, pbuf, lane, power, ea, eb);
+    split_power(v, xbuf, pbuf, lane, power, nza, nzb, ea, eb);
     for (int k = lane; k < NBINS; k += 64) {
         const float2 pw = pbuf[k];
         spec[(size_t)fa * NBINS + k] = pw.x;

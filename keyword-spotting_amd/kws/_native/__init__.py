@@ -29,7 +29,7 @@ SIGNATURES = {
     "kws_abi_version": (C.c_int, []),
     "kws_create": (C.c_int, [C.POINTER(_c_ctx), C.c_int]),
     "kws_destroy": (None, [_c_ctx]),
-    "kws_set_stream": (C.c_int, [_c_ctx, C.c_void_p]),
+    "kws_set_stream": (C.c_int, [_c_ctx, C.c_void_p, C.c_int]),
     "kws_sync": (C.c_int, [_c_ctx]),
     "kws_last_error": (C.c_char_p, [_c_ctx]),
     "kws_set_frontend": (C.c_int, [_c_ctx] + [C.c_int] * 7 + [C.c_float, C.c_int]),
@@ -119,10 +119,10 @@ class Context:
         """Enqueue on torch's current stream for this device, so torch sees the work in order."""
         import torch
 
-        self._check(self._lib.kws_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._check(self._lib.kws_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), 1))
 
     def use_own_stream(self):
-        self._check(self._lib.kws_set_stream(self._h, None))
+        self._check(self._lib.kws_set_stream(self._h, None, 0))
 
     def sync(self):
         self._check(self._lib.kws_sync(self._h))
