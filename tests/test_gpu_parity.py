@@ -24,9 +24,16 @@ def native():
     return _native
 
 
+def make_ctx(native):
+    """Context enqueuing on torch's current stream, so tensor fills/copies and kernels are ordered."""
+    c = native.Context(0)
+    c.use_torch_stream()
+    return c
+
+
 @pytest.fixture(scope="module")
 def ctx(native):
-    c = native.Context(0)
+    c = make_ctx(native)
     yield c
     c.close()
 
@@ -109,7 +116,7 @@ def test_mfcc_unaligned_pointer_takes_scalar_path(ctx, dev):
 
 def test_mfcc_other_geometry(native, dev):
     """Half-second clips, 13 cepstra, 40 filters, 8 kHz: exercises the table builder and ragged tail."""
-    c = native.Context(0)
+    c = make_ctx(native)
     try:
         spec = o_mfcc.FrontendSpec(sample_rate=8000, n_samples=4000, winlen=0.032, winstep=0.012, nfft=512, nfilt=40, numcep=13)
         c.set_frontend(sample_rate=8000, n_samples=4000, frame_len=spec.frame_len, frame_step=spec.frame_step,
@@ -250,7 +257,7 @@ def test_infer_matches_oracle(ctx, dev, kind, seed):
 def test_infer_requires_model(native, dev):
     from kws.common.errors import ModelError
 
-    c = native.Context(0)
+    c = make_ctx(native)
     try:
         wav = torch.zeros((2, 16000), dtype=torch.int16, device=dev)
         logits = torch.empty((2, 12), dtype=torch.float32, device=dev)
@@ -345,3 +352,34 @@ def test_python_surface_end_to_end(dev, tmp_path):
     want2 = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(padded)))
     assert [g[0] for g in got] == o_dscnn.predict(want2).tolist()
     assert all(word == spotter.words[idx] for idx, word in got)
+
+
+def test_own_stream_and_profiling_counters(native, dev):
+    """A context on its own (non-blocking) stream: explicit syncs order it against torch; the per-kernel
+    event timers count one launch per kernel per call."""
+    c = native.Context(0)
+    try:
+        c.load_dscnn(o_dscnn.flatten_state(o_dscnn.random_state(seed=1)), 12)
+        clips = synth_clips(32, 8)
+        wav = torch.from_numpy(clips).to(dev)
+        logits = torch.empty((32, 12), dtype=torch.float32, device=dev)
+        labels = torch.empty((32,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        c.prof_enable(True)
+        c.prof_reset()
+        for _ in range(3):
+            c.infer_i16(wav, logits, labels)
+        ms_c, n_c = c.prof_read(native.KWS_K_DSCNN)
+        ms_m, n_m = c.prof_read(native.KWS_K_MFCC)
+        assert (n_c, n_m) == (3, 3) and ms_c > 0 and ms_m > 0
+        c.prof_enable(False)
+        c.sync()
+        ref = make_ctx(native)
+        try:
+            ref.load_dscnn(o_dscnn.flatten_state(o_dscnn.random_state(seed=1)), 12)
+            l2, _ = gpu_infer(ref, dev, clips)
+        finally:
+            ref.close()
+        assert np.array_equal(logits.cpu().numpy(), l2)
+    finally:
+        c.close()
