@@ -55,6 +55,17 @@ def timed_steps(step_fn, steps: int, barrier, device_sync, all_reduce_max):
     return all_reduce_max(time.perf_counter() - t0)
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 read correction applied).  bench.py
+    cannot collect counters itself; None if the file has no entry."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return float(json.load(f)["kernels"][kernel]["hbm_bytes"])
+    except Exception:
+        return None
+
+
 def synth_weights(seed: int = 1, std: float = 0.1) -> np.ndarray:
     """Random-init DS-CNN in state_dict order, every parameter (biases too) ~ N(0, std)."""
     n = 6400 + 64 + 4 * (576 + 64 + 4096 + 64) + NUM_CLASSES * 64 + NUM_CLASSES
@@ -197,7 +208,9 @@ def main():
                 "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(_native.kernel_name(_native.KWS_K_DSCNN)),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+                "algorithmic_bytes_per_launch": B * (99 * 10 * 4 + 52),
                 "avg_kernel_ms": dscnn_s * 1e3,
                 "launches": k_n,
                 "flop_per_clip": DSCNN_FLOP_PER_CLIP,
