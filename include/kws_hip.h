@@ -114,10 +114,21 @@ int kws_reserve(kws_ctx* ctx, int max_batch);
 /* Debug/parity aid: run the DS-CNN and also store every stored activation per clip to d_act
  * (float32 [B, KWS_ACT_FLOATS_PER_CLIP]): conv1 out [64][47*3], block1 out interior [64][47*3],
  * block2 out interior [64][49*5], block3 out interior [64][51*7], pooled mean [64].  "Interior" =
- * the pointwise output without the relu(bias) ring its padding=1 adds (models.py:104-106). */
+ * the pointwise output without the relu(bias) ring its padding=1 adds (models.py:104-106).
+ * use_mfma: 1 = the product kernel, 0 = a variant whose pointwise / conv1 GEMMs run on the VALU (an
+ * independent check of the matrix-core operand mapping). */
 #define KWS_ACT_FLOATS_PER_CLIP (64 * (141 + 141 + 245 + 357) + 64)
 int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label,
                           float* d_act, int use_mfma);
+
+/* Diagnostics: the same forward with per-clip shader-clock stamps (s_memtime of thread 0) at the phase
+ * boundaries of the DS-CNN kernel, uint64 [B, KWS_DSCNN_STAMPS]: 0 start, 1 features staged, 2/3 conv1
+ * done / barrier, 4/5 .. 10/11 blocks 1..4 done / barrier, 12 end; [14], [15] = 100 MHz real-time
+ * counter at start / end.  mode: 1 = the product kernel, 0 = VALU cross-check variant, 2 / 3 = timing
+ * ablations (matrix core only / stencil only: wrong results by construction).  Never used on the
+ * product path. */
+#define KWS_DSCNN_STAMPS 16
+int kws_forward_stamps_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode);
 
 /* ---- sigproc operators (kws/libs/speech_features/sigproc.py) -------------------------------- */
 

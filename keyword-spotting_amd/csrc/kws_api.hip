@@ -439,24 +439,30 @@ int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
 }
 
 static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
-                        bool use_mfma, const char* fn) {
+                        int mode, const char* fn, unsigned long long* d_stamps = nullptr) {
     int rc = check_batch(c, d_feat, B, fn);
     if (rc) return rc;
     if (!d_logits) return fail(c, KWS_EINVAL, std::string(fn) + ": d_logits is NULL");
     if (!c->model_ready) return fail(c, KWS_ESTATE, std::string(fn) + ": no model loaded (kws_load_dscnn)");
     HIP_TRY(c, hipSetDevice(c->device));
     ProfScope ps(c, KWS_K_DSCNN);
-    HIP_TRY(c, launch_dscnn(c->stream, c->mw, d_feat, B, d_logits, d_label, d_act, use_mfma));
+    HIP_TRY(c, launch_dscnn(c->stream, c->mw, d_feat, B, d_logits, d_label, d_act, mode, d_stamps));
     return KWS_OK;
 }
 
 int kws_forward_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label) {
-    return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, true, "kws_forward_f32");
+    return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, 1, "kws_forward_f32");
 }
 
 int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                           int use_mfma) {
-    return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma != 0, "kws_forward_debug_f32");
+    return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma, "kws_forward_debug_f32");
+}
+
+int kws_forward_stamps_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode) {
+    if (!d_stamps) return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: d_stamps is NULL");
+    return forward_impl(c, d_feat, B, d_logits, nullptr, nullptr, mode, "kws_forward_stamps_f32",
+                        reinterpret_cast<unsigned long long*>(d_stamps));
 }
 
 int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label) {
@@ -469,7 +475,7 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     if (rc) return rc;
     rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
     if (rc) return rc;
-    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, true, "kws_infer_i16");
+    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, 1, "kws_infer_i16");
 }
 
 // ---- sigproc operators --------------------------------------------------------------------------

@@ -8,23 +8,31 @@
 //   4 x { depthwise 3x3 pad 1 ; pointwise 1x1 *padding=1* ; ReLU }  -> 64 x (49x5, 51x7, 53x9, 55x11)
 //   global average pool, Linear(64 -> C), argmax (first maximum wins)
 //
-// The reference's 1x1 convolution with padding=1 surrounds each block's output with a ring equal to
-// relu(bias) (models.py:104-106).  The ring is never stored: each channel plane in LDS holds only the
-// "interior" H x W values followed by two extra slots, [P] = relu(bias[c]) and [P+1] = 0.  A depthwise
-// tap that falls on the ring reads slot P, one that falls outside the padded map reads slot P+1, so
-// the 3x3 stencil is nine unconditional LDS reads at per-lane precomputed addresses.
+// The relu(bias) ring.  The reference's 1x1 convolution with padding=1 surrounds each block's output
+// with a ring equal to relu(bias) (models.py:104-106).  The ring is never stored: each channel plane in
+// LDS holds only the "interior" H x W values followed by two extra slots, [P] = relu(bias[c]) and
+// [P+1] = 0.  A depthwise tap that falls on the ring reads slot P, one that falls outside the padded
+// map reads slot P+1, so a stencil tap is an unconditional LDS read at a per-lane precomputed address.
 //
 // MFMA mapping (32x32x2, D[i][j] += A[i][k] * B[k][j]): i = output channel, j = position, k = input
-// channel.  Lane l supplies A[i = l&31][k = l>>5] (weights, held in registers for the whole block) and
-// B[k = l>>5][j = l&31]: lane l therefore computes the depthwise output of position l&31 for the
-// input channels 2s + (l>>5), s = 0..31, and feeds it to the matrix core without touching LDS.
+// channel.  Lane l supplies A[i = l&31][k = l>>5] (weights, in registers for the whole block) and
+// B[k = l>>5][j = l&31]: lane l computes the depthwise output of column j for input channels
+// 2s + (l>>5), s = 0..31, and feeds it to the matrix core without touching LDS.
 // D: column = lane&31 (position), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel).
+//
+// Stencil with 3 LDS reads instead of 9.  The 32 MFMA columns of a tile are 30 consecutive output
+// positions plus one halo column on each side.  A lane reads only its own column (rows h-1, h, h+1);
+// because the depthwise weights are the same in all 32 lanes of a half-wave, each lane forms the two
+// 3-tap column sums its right and left neighbours need and hands them over with one DPP wave shift
+// each.  A neighbour that belongs to another row (x == 0 or x == W-1) is outside the zero-padded map,
+// so its contribution is multiplied by a per-lane 0/1 mask.  The reads of step s+2 are in flight while
+// step s is evaluated and the matrix core works through the two MFMAs of the previous step.
 //
 // LDS map (floats): planes are channel-major [64][P+2]
 //   Z3 (block3 out, 51x7)  @ 0      .. 22976     Z2 (block2 out, 49x5) @ 22976 .. 38784
 //   Z1 (block1 out, 47x3)  @ 0      .. 9152      Z0 (conv1 out, 47x3)  @ 9152  .. 18304
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
-//   misc                   @ 38784  .. 40960     depthwise table, pool scratch
+//   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled
 #include "kws_internal.h"
 
 namespace kws {
@@ -32,19 +40,25 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int NW = 8;          // wavefronts per workgroup
-constexpr int NT = NW * 64;    // 512 threads
+#ifndef KWS_DSCNN_WAVES
+#define KWS_DSCNN_WAVES 8
+#endif
+constexpr int NW = KWS_DSCNN_WAVES;  // wavefronts per workgroup (8 = 2 per SIMD; 12 = 3 per SIMD measured slower)
+constexpr int NT = NW * 64;
+constexpr int TW = 30;               // output positions per tile (32 MFMA columns - 2 halo columns)
 
 constexpr int P0 = C1_H * C1_W;                  // 141
 constexpr int FEAT_H = 103, FEAT_W = 14;         // MFCC zero-padded by 2 (top/left) and up to the conv1 reach
 constexpr int OFF_Z3 = 0, OFF_Z2 = 22976, OFF_Z1 = 0, OFF_Z0 = 9152, OFF_FEAT = 18304;
-constexpr int OFF_DWTAB = 38784;                 // [64][12]
-constexpr int OFF_POOLBUF = OFF_DWTAB + 768;     // [NW][64]
-constexpr int OFF_POOLED = OFF_POOLBUF + NW * 64;// [64]
-constexpr int OFF_PWB = OFF_POOLED + 64;         // [64] pointwise bias of the running block
+constexpr int OFF_DWTAB = 38784;                 // [2][64][12]  double-buffered per block
+constexpr int OFF_PWB = OFF_DWTAB + 2 * 768;     // [2][64]      pointwise bias, double-buffered
+constexpr int OFF_POOLED = OFF_PWB + 2 * 64;     // [64]
+constexpr int OFF_POOLBUF = OFF_DWTAB;           // [NW][64] aliases depthwise buffer 0 (idle during block 4)
 constexpr int LDS_FLOATS = 40960;                // 160 KiB
-static_assert(OFF_PWB + 64 <= LDS_FLOATS, "LDS overflow");
+static_assert(OFF_POOLED + 64 <= LDS_FLOATS, "LDS overflow");
+static_assert(NW * 64 <= 768, "pool scratch must fit one depthwise buffer");
 static_assert(OFF_FEAT + FEAT_H * FEAT_W <= OFF_Z2, "feature pad overlaps Z2");
+static_assert(CH * 12 <= 2 * NT, "table staging assumes at most two elements per thread");
 
 // Geometry of block N (1..4): output plane H x W (all of it is the next block's interior).
 template <int N>
@@ -56,24 +70,74 @@ struct Blk {
     static constexpr int POUT = H * W, SOUT = POUT + 2;
     static constexpr int OFF_IN = N == 1 ? OFF_Z0 : N == 2 ? OFF_Z1 : N == 3 ? OFF_Z2 : OFF_Z3;
     static constexpr int OFF_OUT = N == 1 ? OFF_Z1 : N == 2 ? OFF_Z2 : OFF_Z3;  // block 4 stores nothing
-    static constexpr int TILES = (POUT + 31) / 32;
+    static constexpr int TILES = (POUT + TW - 1) / TW;
+    static constexpr int BUF = (N - 1) & 1;                       // which depthwise / bias buffer it reads
 };
 
 __device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// lane i <- lane i-1 / lane i+1 across the whole wavefront (0 shifted in at the ends)
+__device__ __forceinline__ float from_lane_below(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+
+// Sum over each 32-lane half of the wavefront without touching LDS: inclusive scan inside the 16-lane rows
+// (row_shr 1,2,4,8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15).  Lanes 31 and 63 hold the totals.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift_add(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+    return v + o;
+}
+__device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
+    v = dpp_shift_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_shift_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_shift_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+// Depthwise table [64][12] and pointwise bias [64] of block n (1..4) go to LDS buffer (n-1)&1 in two
+// halves so the global-memory latency hides under a whole phase: fetch() issues the loads into three
+// registers at the start of the previous phase, store() writes them to LDS after that phase's units.
+struct BlockTables {
+    float d0, d1, b;
+};
+__device__ __forceinline__ void fetch_block_tables(const DscnnWeights& w, int n, int tid, BlockTables& r) {
+    const float* src = w.dw_w + (n - 1) * CH * 12;
+    r.d0 = tid < CH * 12 ? src[tid] : 0.f;
+    r.d1 = NT + tid < CH * 12 ? src[NT + tid] : 0.f;
+    r.b = tid < CH ? w.pw_b[(n - 1) * CH + tid] : 0.f;
+}
+__device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r) {
+    float* dwtab = lds + OFF_DWTAB + ((n - 1) & 1) * 768;
+    if (tid < CH * 12) dwtab[tid] = r.d0;
+    if (NT + tid < CH * 12) dwtab[NT + tid] = r.d1;
+    if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b;
+}
+
+// Pointwise weights of block n as MFMA A operands: wa[ct][s] = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)].
+__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, float (&wa)[2][32]) {
+    const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wa[ct][s] = pw[2 * s * CH + ct * 32];
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv1: D[cout][pos] = sum_k W[cout][k] * im2col[k][pos], k = kh*10 + kw, as 50 MFMA k-steps.
 template <bool MFMA>
-__device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, int tid) {
+__device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, int tid, const float (&a)[50]) {
     const float* featp = lds + OFF_FEAT;
     float* z0 = lds + OFF_Z0;
     if constexpr (MFMA) {
         const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
-        const int ct = wv & 1;  // units u = wv, wv + 8 share the output-channel tile
-        float a[50];
-#pragma unroll
-        for (int s = 0; s < 50; ++s) a[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
+        const int ct = wv & 1;  // units u = wv, wv + NW share the output-channel tile (NW is even)
         for (int u = wv; u < 10; u += NW) {
             const int pt = u >> 1;
             const int pos = pt * 32 + col;
@@ -112,104 +176,97 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// One depthwise-separable block.  psum (block 4 only): per-lane partial sums of relu outputs for the
-// global average pool, indexed like the MFMA accumulators ([ct][r]) or by output channel (VALU path).
-template <int N, bool MFMA>
-__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid) {
+// One depthwise-separable block.  wa: pointwise weights of THIS block on entry; on exit (N < 4) the
+// loads of the next block's weights have been issued into it, so they fly across the barrier.
+// MODE: 0 = pointwise GEMM on the VALU (cross-check of the MFMA operand mapping), 1 = product path,
+// 2 / 3 = timing ablations (matrix core only / stencil only; wrong results by construction).
+template <int N, int MODE>
+__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, float (&wa)[2][32]) {
     using G = Blk<N>;
+    constexpr bool MFMA = MODE != 0;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
     float* zout = lds + G::OFF_OUT;
-    float* dwtab = lds + OFF_DWTAB;
+    const float* dwtab = lds + OFF_DWTAB + G::BUF * 768;
+    const float* pwb = lds + OFF_PWB + G::BUF * 64;
     float* poolbuf = lds + OFF_POOLBUF;
-    const float* pw_w = w.pw_w + (N - 1) * CH * CH;
-    const float* pw_b = w.pw_b + (N - 1) * CH;
 
-    // stage this block's depthwise table [64][12]; ring / zero slots of the output planes
-    for (int i = tid; i < CH * 12; i += NT) dwtab[i] = w.dw_w[(N - 1) * CH * 12 + i];
-    if (tid < CH) {
-        const float b = pw_b[tid];
-        lds[OFF_PWB + tid] = b;
-        if (N < 4) {
-            zout[tid * G::SOUT + G::POUT] = relu(b);
+    // The other table buffer is idle during this block: the next block's tables are fetched now and
+    // stored after the units.  Ring and zero slots of the output planes.  No barrier needed before the
+    // units: everything they read was staged during the previous phase.
+    BlockTables next_tables;
+    if constexpr (N < 4) {
+        fetch_block_tables(w, N + 1, tid, next_tables);
+        if (tid < CH) {
+            zout[tid * G::SOUT + G::POUT] = relu(pwb[tid]);
             zout[tid * G::SOUT + G::POUT + 1] = 0.f;
         }
+    } else if (!MFMA) {
+        poolbuf[wv * CH + lane] = 0.f;  // the VALU path accumulates into its wave's scratch row
     }
-    __syncthreads();
 
-    // pointwise weights / bias for this lane
-    float wa[2][32];
-    if constexpr (MFMA) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-            for (int s = 0; s < 32; ++s) wa[ct][s] = pw_w[(2 * s + half) * CH + ct * 32 + col];
-        }
-    }
     // accumulator rows 4q..4q+3 of tile ct are output channels ct*32 + 8q + 4*half + (0..3): one float4
-    const float4* bias4 = reinterpret_cast<const float4*>(lds + OFF_PWB) + half;
+    const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 3;
     float psum[2][16];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) psum[ct][r] = 0.f;
+
     for (int t = wv; t < G::TILES; t += NW) {
-        const int pos = t * 32 + col;
-        const bool valid = pos < G::POUT;
-        const int posc = valid ? pos : G::POUT - 1;
+        // column j of the tile is output position t*TW - 1 + j: columns 0 and 31 are halo
+        const int pos = t * TW - 1 + col;
+        const bool valid = col >= 1 && col <= TW && pos < G::POUT;
+        const int posc = pos < 0 ? 0 : (pos < G::POUT ? pos : G::POUT - 1);
         const int h = posc / G::W, x = posc % G::W;
-        // nine tap addresses (float index inside this lane's first channel plane)
-        int ta[9];
+        const float mask_l = x > 0 ? 1.f : 0.f, mask_r = x < G::W - 1 ? 1.f : 0.f;
+        // own-column tap addresses (rows h-1, h, h+1), as float indices into lds, for channel pairs
+        // 0..15 (lo) and 16..31 (hi): two bases keep every ds_read inside the 64 KiB immediate window;
+        // the empty asm stops the compiler from re-deriving one base register per step.
+        int tlo[3], thi[3];
 #pragma unroll
         for (int dh = -1; dh <= 1; ++dh) {
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int o = G::RING ? 1 : 0;
-                const int hh = h + dh - o, xx = x + dx - o;
-                const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
-                const bool in_map = (unsigned)(h + dh) < (unsigned)G::H && (unsigned)(x + dx) < (unsigned)G::W;
-                int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
-                ta[(dh + 1) * 3 + (dx + 1)] = a + half * G::SIN;
-            }
+            const int o = G::RING ? 1 : 0;
+            const int hh = h + dh - o, xx = x - o;
+            const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
+            const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
+            const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
+            tlo[dh + 1] = G::OFF_IN + a + half * G::SIN;
+            thi[dh + 1] = tlo[dh + 1] + 32 * G::SIN;
+            asm volatile("" : "+v"(tlo[dh + 1]));
+            asm volatile("" : "+v"(thi[dh + 1]));
         }
-        // Two pointer sets (channel pairs 0..15 and 16..31) keep every ds_read inside the 64 KiB
-        // immediate-offset window; the empty asm stops the compiler from re-deriving one base per step.
-        int tlo[9], thi[9];  // float indices into lds
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            tlo[i] = G::OFF_IN + ta[i];
-            thi[i] = tlo[i] + 32 * G::SIN;
-            asm volatile("" : "+v"(tlo[i]));
-            asm volatile("" : "+v"(thi[i]));
-        }
-        // depthwise 3x3 (+bias) of channel 2s + half at this lane's position -> one MFMA B operand.
-        // Split into "issue the 12 LDS reads" and "9 FMAs" so the reads of step s+1 can be in flight
-        // while step s is consumed.
-        const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 3;
+
         struct Taps {
-            float4 q0, q1, q2;
-            float x[9];
+            float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
+            float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
         };
-        auto dw_load = [&](int s, Taps& t) {
-            t.q0 = dwt4[s * 6 + 0];
-            t.q1 = dwt4[s * 6 + 1];
-            t.q2 = dwt4[s * 6 + 2];
-            const int* tp = s < 16 ? tlo : thi;
+        auto dw_load = [&](int s, Taps& tp) {
+            tp.q0 = dwt4[s * 6 + 0];
+            tp.q1 = dwt4[s * 6 + 1];
+            tp.q2 = dwt4[s * 6 + 2];
+            const int* ta = s < 16 ? tlo : thi;
             const int o = 2 * (s & 15) * G::SIN;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) t.x[i] = lds[tp[i] + o];
+            tp.up = lds[ta[0] + o];
+            tp.mid = lds[ta[1] + o];
+            tp.dn = lds[ta[2] + o];
         };
-        auto dw_eval = [&](const Taps& t) -> float {
-            float acc = t.q2.y;  // bias
-            acc = fmaf(t.q0.x, t.x[0], acc);
-            acc = fmaf(t.q0.y, t.x[1], acc);
-            acc = fmaf(t.q0.z, t.x[2], acc);
-            acc = fmaf(t.q0.w, t.x[3], acc);
-            acc = fmaf(t.q1.x, t.x[4], acc);
-            acc = fmaf(t.q1.y, t.x[5], acc);
-            acc = fmaf(t.q1.z, t.x[6], acc);
-            acc = fmaf(t.q1.w, t.x[7], acc);
-            acc = fmaf(t.q2.x, t.x[8], acc);
-            return acc;
+        // depthwise 3x3 (+bias) of channel 2s + half at this lane's column -> one MFMA B operand
+        auto dw_eval = [&](const Taps& tp) -> float {
+            float c = tp.q2.y;                                     // bias
+            c = fmaf(tp.q0.y, tp.up, c);                           // (dh,dx) = (-1, 0)
+            c = fmaf(tp.q1.x, tp.mid, c);                          //           ( 0, 0)
+            c = fmaf(tp.q1.w, tp.dn, c);                           //           (+1, 0)
+            // The weights are the same in all 32 lanes of a half, so the column sums for the right-hand
+            // and left-hand neighbours are formed here, at the source lane, and shifted once each.
+            float to_right = tp.q0.x * tp.up;                      // what lane+1 needs: its (.., -1) taps
+            to_right = fmaf(tp.q0.w, tp.mid, to_right);
+            to_right = fmaf(tp.q1.z, tp.dn, to_right);
+            float to_left = tp.q0.z * tp.up;                       // what lane-1 needs: its (.., +1) taps
+            to_left = fmaf(tp.q1.y, tp.mid, to_left);
+            to_left = fmaf(tp.q2.x, tp.dn, to_left);
+            c = fmaf(mask_l, from_lane_below(to_right), c);
+            return fmaf(mask_r, from_lane_above(to_left), c);
         };
 
         if constexpr (MFMA) {
@@ -220,41 +277,72 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 acc0[4 * q + 0] = b0.x; acc0[4 * q + 1] = b0.y; acc0[4 * q + 2] = b0.z; acc0[4 * q + 3] = b0.w;
                 acc1[4 * q + 0] = b1.x; acc1[4 * q + 1] = b1.y; acc1[4 * q + 2] = b1.z; acc1[4 * q + 3] = b1.w;
             }
-            // software pipeline: the LDS reads of step s+1 are issued before step s is evaluated, and
-            // the matrix core works on step s while the VALU/LDS side runs ahead
-            Taps tp0, tp1;
-            dw_load(0, tp0);
+            // software pipeline, two steps deep: reads of step s+2 are issued before step s is evaluated
+            Taps ta0, ta1;
+            dw_load(0, ta0);
+            dw_load(1, ta1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 32; s += 2) {
-                dw_load(s + 1, tp1);
-                const float y0 = dw_eval(tp0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s + 2 < 32) dw_load(s + 2, tp0);
-                const float y1 = dw_eval(tp1);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MODE == 1) {
+                    const float y0 = dw_eval(ta0);
+                    if (s + 2 < 32) dw_load(s + 2, ta0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
+                    const float y1 = dw_eval(ta1);
+                    if (s + 3 < 32) dw_load(s + 3, ta1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
+                } else if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
+                    const float y0 = ta0.mid, y1 = ta1.mid;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
+                } else {  // MODE 3, timing ablation: stencil only (results are wrong)
+                    const float y0 = dw_eval(ta0);
+                    if (s + 2 < 32) dw_load(s + 2, ta0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc0[0] += y0 * wa[0][s];
+                    const float y1 = dw_eval(ta1);
+                    if (s + 3 < 32) dw_load(s + 3, ta1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc1[0] += y1 * wa[1][s + 1];
+                }
             }
-            if constexpr (N < 4) {
-                if (valid) {
+            auto epilogue = [&]() {
+                if constexpr (N < 4) {
+                    if (valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            zout[row_of(r, half) * G::SOUT + pos] = relu(acc0[r]);
+                            zout[(32 + row_of(r, half)) * G::SOUT + pos] = relu(acc1[r]);
+                        }
+                    }
+                } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        zout[row_of(r, half) * G::SOUT + pos] = relu(acc0[r]);
-                        zout[(32 + row_of(r, half)) * G::SOUT + pos] = relu(acc1[r]);
+                        psum[0][r] += valid ? relu(acc0[r]) : 0.f;
+                        psum[1][r] += valid ? relu(acc1[r]) : 0.f;
                     }
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    psum[0][r] += valid ? relu(acc0[r]) : 0.f;
-                    psum[1][r] += valid ? relu(acc1[r]) : 0.f;
-                }
+            };
+            // this wave's last unit: the A operands are dead, so the next block's are fetched now and the
+            // loads fly under the epilogue, the barrier and the next prologue
+            if (N < 4 && t + NW >= G::TILES) {
+                __builtin_amdgcn_sched_barrier(0);  // not before the last MFMA has read the old operands
+                if constexpr (N < 4) load_pointwise(w, N + 1, lane, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                epilogue();
+                break;
             }
+            epilogue();
         } else {
             // VALU cross-check of the pointwise GEMM: each half sums its 32 input channels, halves are
             // combined with a lane exchange.
+            const float* pw_w = w.pw_w + (N - 1) * CH * CH;
             float y[32];
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
@@ -267,11 +355,11 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 float part = 0.f;
 #pragma unroll
                 for (int s = 0; s < 32; ++s) part = fmaf(pw_w[(2 * s + half) * CH + co], y[s], part);
-                const float tot = relu(part + __shfl_xor(part, 32, 64) + pw_b[co]);
+                const float tot = relu(part + __shfl_xor(part, 32, 64) + pwb[co]);
                 if constexpr (N < 4) {
                     if (valid && half == 0) zout[co * G::SOUT + pos] = tot;
                 } else {
-                    // pool: sum this tile's 32 positions and accumulate into the wave's own scratch row
+                    // pool: sum this tile's positions and accumulate into the wave's own scratch row
                     float sum = (valid && half == 0) ? tot : 0.f;
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -281,28 +369,32 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
         }
     }
 
-    if constexpr (N == 4 && MFMA) {
-        // reduce the pool partials over the 32 positions held by each half-wave
+    if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
+    if constexpr (MFMA) {
+        if constexpr (N < 4) {
+            if (wv >= G::TILES) load_pointwise(w, N + 1, lane, wa);  // waves without a unit in this block
+        } else {
+            // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+            for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = psum[ct][r];
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-                if (col == 0) poolbuf[wv * CH + ct * 32 + row_of(r, half)] = s;
+                for (int r = 0; r < 16; ++r) {
+                    const float s = half_wave_sum_to_last_lane(psum[ct][r]);
+                    if (col == 31) poolbuf[wv * CH + ct * 32 + row_of(r, half)] = s;
+                }
             }
         }
     }
     (void)bias4;
-    (void)wa;
 }
 
-template <bool MFMA>
+template <int MODE>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
-                                                           float* __restrict__ act) {
+                                                           float* __restrict__ act,
+                                                           unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool MFMA = MODE != 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
 
@@ -310,86 +402,134 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     // loop costs more registers than the relaunch saves).
     const int clip = blockIdx.x;
     if (clip >= B) return;
-    {
-        // ---- phase 0: MFCC map -> zero-padded [103][14] in LDS; clear the pool scratch ----------
-        float* featp = lds + OFF_FEAT;
-        for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
-        for (int i = tid; i < NW * CH; i += NT) lds[OFF_POOLBUF + i] = 0.f;
-        __syncthreads();
-        const float* f = feat + (size_t)clip * (IN_T * IN_F);
-        for (int i = tid; i < IN_T * IN_F; i += NT) featp[(i / IN_F + 2) * FEAT_W + (i % IN_F) + 2] = f[i];
-        __syncthreads();
+    // diagnostics only (stamps == nullptr in every product call): shader-clock stamps of thread 0 at the
+    // phase boundaries, KWS_DSCNN_STAMPS per clip; [14] and [15] carry the 100 MHz real-time counter
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + n_stamp] = __builtin_amdgcn_s_memtime();
+        ++n_stamp;
+    };
+    if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 2] = __builtin_amdgcn_s_memrealtime();
+    stamp();  // 0: start
 
-        conv1_phase<MFMA>(w, lds, tid);
-        __syncthreads();
-        float* a = act ? act + (size_t)clip * KWS_ACT_FLOATS_PER_CLIP : nullptr;
-        if (a) {
-            for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + (i / P0) * (P0 + 2) + i % P0];
-            a += CH * P0;
-        }
-
-        block_phase<1, MFMA>(w, lds, tid);
-        __syncthreads();
-        if (a) {
-            for (int i = tid; i < CH * Blk<1>::POUT; i += NT)
-                a[i] = lds[OFF_Z1 + (i / Blk<1>::POUT) * Blk<1>::SOUT + i % Blk<1>::POUT];
-            a += CH * Blk<1>::POUT;
-        }
-        block_phase<2, MFMA>(w, lds, tid);
-        __syncthreads();
-        if (a) {
-            for (int i = tid; i < CH * Blk<2>::POUT; i += NT)
-                a[i] = lds[OFF_Z2 + (i / Blk<2>::POUT) * Blk<2>::SOUT + i % Blk<2>::POUT];
-            a += CH * Blk<2>::POUT;
-        }
-        block_phase<3, MFMA>(w, lds, tid);
-        __syncthreads();
-        if (a) {
-            for (int i = tid; i < CH * Blk<3>::POUT; i += NT)
-                a[i] = lds[OFF_Z3 + (i / Blk<3>::POUT) * Blk<3>::SOUT + i % Blk<3>::POUT];
-            a += CH * Blk<3>::POUT;
-        }
-        block_phase<4, MFMA>(w, lds, tid);
-        __syncthreads();
-
-        // ---- global average pool over 55 x 11 = 477 interior + 128 ring positions ---------------
-        float* pooled = lds + OFF_POOLED;
-        if (tid < CH) {
-            float s = 0.f;
+    // ---- phase 0: weight loads in flight, MFCC map -> zero-padded [103][14] in LDS ------------------
+    float a1[50];        // conv1 weights of this wave's output-channel tile (MFMA A operands)
+    float wa[2][32];     // pointwise weights of the running block
+    if constexpr (MFMA) {
+        const int half = lane >> 5, col = lane & 31, ct = wv & 1;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) s += lds[OFF_POOLBUF + k * CH + tid];
-            constexpr float RING_N = 55.f * 11.f - 53.f * 9.f;  // 128
-            s = fmaf(RING_N, relu(w.pw_b[3 * CH + tid]), s) * (1.0f / (55.f * 11.f));
-            pooled[tid] = s;
-            if (a) a[tid] = s;
-        }
-        __syncthreads();
-
-        // ---- Linear(64 -> C) + argmax (first maximum wins) on wavefront 0 ------------------------
-        if (wv == 0) {
-            const int C = w.num_classes;
-            float v = -INFINITY;
-            if (lane < C) {
-                float acc = w.fc_b[lane];
-                const float* wr = w.fc_w + lane * CH;
-#pragma unroll 8
-                for (int c = 0; c < CH; ++c) acc = fmaf(wr[c], pooled[c], acc);
-                logits[(size_t)clip * C + lane] = acc;
-                v = acc;
-            }
-            int idx = lane < C ? lane : 0x7fffffff;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const float ov = __shfl_xor(v, o, 64);
-                const int oi = __shfl_xor(idx, o, 64);
-                if (ov > v || (ov == v && oi < idx)) {
-                    v = ov;
-                    idx = oi;
-                }
-            }
-            if (label && lane == 0) label[clip] = idx;
-        }
+        for (int s = 0; s < 50; ++s) a1[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
+        load_pointwise(w, 1, lane, wa);
     }
+    float* featp = lds + OFF_FEAT;
+    const float* f = feat + (size_t)clip * (IN_T * IN_F);
+    constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
+    float fv[FV];
+#pragma unroll
+    for (int k = 0; k < FV; ++k) fv[k] = (tid + k * NT) < IN_T * IN_F ? f[tid + k * NT] : 0.f;
+    for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
+    {
+        BlockTables t1;
+        fetch_block_tables(w, 1, tid, t1);
+        store_block_tables(lds, 1, tid, t1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FV; ++k) {
+        const int i = tid + k * NT;
+        if (i < IN_T * IN_F) featp[(i / IN_F + 2) * FEAT_W + (i % IN_F) + 2] = fv[k];
+    }
+    __syncthreads();
+    stamp();  // 1: features staged
+
+    conv1_phase<MFMA>(w, lds, tid, a1);
+    stamp();  // 2: conv1 units of wave 0 done
+    __syncthreads();
+    stamp();  // 3: conv1 barrier
+    float* a = act ? act + (size_t)clip * KWS_ACT_FLOATS_PER_CLIP : nullptr;
+    if (a) {
+        for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + (i / P0) * (P0 + 2) + i % P0];
+        a += CH * P0;
+    }
+
+    block_phase<1, MODE>(w, lds, tid, wa);
+    stamp();  // 4: block 1 units of wave 0 done
+    __syncthreads();
+    stamp();  // 5: block 1 barrier
+    if (a) {
+        for (int i = tid; i < CH * Blk<1>::POUT; i += NT)
+            a[i] = lds[OFF_Z1 + (i / Blk<1>::POUT) * Blk<1>::SOUT + i % Blk<1>::POUT];
+        a += CH * Blk<1>::POUT;
+    }
+    block_phase<2, MODE>(w, lds, tid, wa);
+    stamp();  // 6
+    __syncthreads();
+    stamp();  // 7
+    if (a) {
+        for (int i = tid; i < CH * Blk<2>::POUT; i += NT)
+            a[i] = lds[OFF_Z2 + (i / Blk<2>::POUT) * Blk<2>::SOUT + i % Blk<2>::POUT];
+        a += CH * Blk<2>::POUT;
+    }
+    block_phase<3, MODE>(w, lds, tid, wa);
+    stamp();  // 8
+    __syncthreads();
+    stamp();  // 9
+    if (a) {
+        for (int i = tid; i < CH * Blk<3>::POUT; i += NT)
+            a[i] = lds[OFF_Z3 + (i / Blk<3>::POUT) * Blk<3>::SOUT + i % Blk<3>::POUT];
+        a += CH * Blk<3>::POUT;
+    }
+    block_phase<4, MODE>(w, lds, tid, wa);
+    stamp();  // 10
+    __syncthreads();
+    stamp();  // 11
+
+    // ---- global average pool over 55 x 11 = 477 interior + 128 ring positions ---------------------
+    float* pooled = lds + OFF_POOLED;
+    if (tid < CH) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) s += lds[OFF_POOLBUF + k * CH + tid];
+        constexpr float RING_N = 55.f * 11.f - 53.f * 9.f;  // 128
+        s = fmaf(RING_N, relu(w.pw_b[3 * CH + tid]), s) * (1.0f / (55.f * 11.f));
+        pooled[tid] = s;
+        if (a) a[tid] = s;
+    }
+    __syncthreads();
+
+    // ---- Linear(64 -> C) + argmax (first maximum wins) on wavefront 0 ------------------------------
+    if (wv == 0) {
+        const int C = w.num_classes;
+        float v = -INFINITY;
+        if (lane < C) {
+            float acc = w.fc_b[lane];
+            const float4* wr = reinterpret_cast<const float4*>(w.fc_w + lane * CH);
+            const float4* pl = reinterpret_cast<const float4*>(pooled);
+#pragma unroll
+            for (int c = 0; c < CH / 4; ++c) {
+                const float4 a4 = wr[c], p4 = pl[c];
+                acc = fmaf(a4.x, p4.x, acc);
+                acc = fmaf(a4.y, p4.y, acc);
+                acc = fmaf(a4.z, p4.z, acc);
+                acc = fmaf(a4.w, p4.w, acc);
+            }
+            logits[(size_t)clip * C + lane] = acc;
+            v = acc;
+        }
+        int idx = lane < C ? lane : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ov > v || (ov == v && oi < idx)) {
+                v = ov;
+                idx = oi;
+            }
+        }
+        if (label && lane == 0) label[clip] = idx;
+    }
+    stamp();  // 12: pool + fc + argmax done
+    if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace
@@ -397,21 +537,27 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 // The kernel needs the CU's whole 160 KiB of LDS as dynamic shared memory: opt in once per device.
 hipError_t dscnn_init_device() {
     const int lds = LDS_FLOATS * (int)sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>)};
+    for (const void* k : kernels) {
+        hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
-                        int32_t* d_label, float* d_act, bool use_mfma) {
+                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps) {
     const size_t lds = LDS_FLOATS * sizeof(float);
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
-    if (use_mfma)
-        hipLaunchKernelGGL(kws_dscnn_fwd_kernel<true>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act);
-    else
-        hipLaunchKernelGGL(kws_dscnn_fwd_kernel<false>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act);
+    // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /
+    // stencil only; wrong results by construction, reachable only through the diagnostics entry point)
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
+        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
+        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
+        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
+    }
     return hipGetLastError();
 }
 

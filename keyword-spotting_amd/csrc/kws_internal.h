@@ -87,7 +87,7 @@ struct DscnnWeights {
 
 hipError_t dscnn_init_device();
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
-                        int32_t* d_label, float* d_act, bool use_mfma);
+                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr);
 
 extern const char* const kKernelNames[KWS_K_COUNT];
 

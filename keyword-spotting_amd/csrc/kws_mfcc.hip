@@ -59,34 +59,49 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     v[7] = csub(e1, e3);
 }
 
-constexpr int XROW = 72;  // complex row stride of the exchange buffer (64 + 8: conflict-free column reads)
+// Complex row strides of the two register<->LDS exchanges.  72 (64 + 8) makes the strided column gather of
+// the first exchange conflict-free for ds_read_b64; 66 puts the sixteen 64-byte row segments that one
+// ds_read_b128 lane group fetches in the second exchange on sixteen different 16-byte slots.
+constexpr int XROW1 = 72, XROW2 = 66;
+
+// Every workgroup is ONE wavefront: LDS instructions of a wavefront execute in order, so data written by one
+// lane is visible to a later read of another lane without s_barrier or s_waitcnt; only the compiler has to
+// keep the order.
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Spectrum buffer index swizzle: lane (k1, q) stores bin k1 + 8q + 64d; without the XOR sixteen lanes of a
+// ds_write_b64 group hit four bank pairs (4-way conflict).
+__device__ __forceinline__ int zswz(int k) { return k ^ ((k >> 3) & 7); }
 
 // 512-point complex FFT across one wavefront.
 //   in : lane l holds z[64*n1 + l] in v[n1]
 //   out: lane l (k1 = l>>3, c = l&7) holds Z[k1 + 8*c + 64*d] in v[d]
-// xbuf: 8*XROW complex of LDS private to the wavefront.
+// xbuf: 8*XROW1 complex of LDS private to the wavefront.
 __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], const cf (&t2)[8], int lane) {
     const int k1 = lane >> 3, q = lane & 7;
     dft8(v);  // over n1 -> k1 (register index)
 #pragma unroll
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], t1[i]);  // W512^(lane*k1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xbuf[i * XROW + lane] = v[i];
-    __syncthreads();
+    for (int i = 0; i < 8; ++i) xbuf[i * XROW1 + lane] = v[i];
+    wave_lds_order();
     // lane (k1, b=q): gather y[k1][8a + b], a = 0..7
 #pragma unroll
-    for (int a = 0; a < 8; ++a) v[a] = xbuf[k1 * XROW + 8 * a + q];
-    __syncthreads();
+    for (int a = 0; a < 8; ++a) v[a] = xbuf[k1 * XROW1 + 8 * a + q];
+    wave_lds_order();
     dft8(v);  // over a -> c
 #pragma unroll
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], t2[i]);  // W64^(b*c)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xbuf[k1 * XROW + 8 * c + q] = v[c];
-    __syncthreads();
+    for (int c = 0; c < 8; ++c) xbuf[k1 * XROW2 + 8 * c + q] = v[c];
+    wave_lds_order();
     // lane (k1, c=q): gather u[k1][c][b], b = 0..7 (contiguous)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) v[b] = xbuf[k1 * XROW + 8 * q + b];
-    __syncthreads();
+    for (int b = 0; b < 8; ++b) v[b] = xbuf[k1 * XROW2 + 8 * q + b];
+    wave_lds_order();
     dft8(v);  // over b -> d
 }
 
@@ -117,8 +132,8 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
                                             bool nzb, float& ea, float& eb) {
     const int k1 = lane >> 3, q = lane & 7;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) zbuf[k1 + 8 * q + 64 * d] = v[d];
-    __syncthreads();
+    for (int d = 0; d < 8; ++d) zbuf[zswz(k1 + 8 * q + 64 * d)] = v[d];
+    wave_lds_order();
     ea = 0.f;
     eb = 0.f;
     const float scale = power ? (1.0f / (4.0f * NFFT)) : 0.25f;
@@ -126,7 +141,7 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
     for (int j = 0; j < 5; ++j) {
         const int k = (j < 4) ? lane + 64 * j : 256;
         if (j == 4 && lane != 0) break;
-        cf z = zbuf[k], w = zbuf[(NFFT - k) & (NFFT - 1)];
+        cf z = zbuf[zswz(k)], w = zbuf[zswz((NFFT - k) & (NFFT - 1))];
         float ar = z.x + w.x, ai = z.y - w.y;  // 2*A
         float br = z.y + w.y, bi = z.x - w.x;  // 2*B (up to a unit factor)
         float pa = fmaf(ar, ar, ai * ai) * scale;
@@ -141,7 +156,7 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         ea += pa;
         eb += pb;
     }
-    __syncthreads();
+    wave_lds_order();
 }
 
 constexpr float PSF_EPS = 2.220446049250313e-16f;  // numpy.finfo(float).eps, exactly 2^-52
@@ -215,7 +230,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         fw[i] = t.mel_fw[i * 64 + lane];
     }
     const uint32_t gth = t.mel_gather[lane];
-    __syncthreads();
+    wave_lds_order();
 
     float4* cbuf = reinterpret_cast<float4*>(xbuf);  // 64 float4 chunk partials (aliases the exchange buffer)
 
@@ -258,7 +273,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
             fb_ = fmaf(fw[i], pw.y, fb_);
         }
         cbuf[lane] = make_float4(ra, fa_, rb, fb_);
-        __syncthreads();
+        wave_lds_order();
         if (lane < p.nfilt) {
             const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
             float sa = 0.f, sb = 0.f;
@@ -275,7 +290,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
             lbuf[lane] = logf(sa == 0.f ? PSF_EPS : sa);
             lbuf[64 + lane] = logf(sb == 0.f ? PSF_EPS : sb);
         }
-        __syncthreads();
+        wave_lds_order();
 
         // DCT-II(ortho) x lifter: lane -> (frame f = lane>>5, coefficient i = lane&31)
         {
@@ -300,7 +315,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
                 out[((size_t)clip * p.num_frames + (fa + f)) * p.numcep + i] = acc;
             }
         }
-        __syncthreads();
+        wave_lds_order();
     }
 }
 

@@ -15,7 +15,8 @@ import numpy as np
 
 from kws.common.errors import AudioProcessingError, KWSError, ModelError
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
+# KWS_HIP_LIB selects another build of the same ABI (A/B timing of kernel variants); default is the in-tree library
+LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 KWS_K_MFCC, KWS_K_DSCNN = 0, 1
@@ -41,6 +42,7 @@ SIGNATURES = {
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
     "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
+    "kws_forward_stamps_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, C.c_void_p, C.c_int]),
     "kws_preemphasis_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_float, _f32p]),
     "kws_framesig_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
     "kws_spec512_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p]),
@@ -169,6 +171,9 @@ class Context:
                                             _ptr(act) if act is not None else None, 1 if use_mfma else 0),
             ModelError,
         )
+
+    def forward_stamps_f32(self, feat, logits, stamps, mode=1):
+        self._check(self._lib.kws_forward_stamps_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits), _ptr(stamps), int(mode)), ModelError)
 
     def infer_i16(self, wav, logits, label=None):
         self._check(
