@@ -313,10 +313,10 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     p.numcep = numcep;
     p.append_energy = 1;
     p.preemph = preemph;
-    p.chunk_samples = (2 * MFCC_PAIRS - 1) * frame_step + frame_len;
-    // 16-byte PCM loads: every clip base, every workgroup's first sample and the staged length must be
-    // multiples of 8 samples (the pointer itself is checked per call)
-    p.vec_ok = (n_samples % 8 == 0) && ((2 * MFCC_PAIRS * frame_step) % 8 == 0) && (p.chunk_samples % 8 == 0);
+    p.chunk_samples = (MFCC_FRAMES_PER_WG - 1) * frame_step + frame_len;
+    // 16-byte PCM loads: every clip base and every workgroup's first sample must be multiples of 8 samples
+    // (the pointer itself is checked per call; the tail of a clip falls back to guarded scalar loads)
+    p.vec_ok = (n_samples % 8 == 0) && ((MFCC_FRAMES_PER_WG * frame_step) % 8 == 0);
     c->sample_rate = sample_rate;
     c->ceplifter = ceplifter;
     c->fe_ready = true;

@@ -11,12 +11,20 @@
 namespace kws {
 
 // ------------------------------------------------------------------------------------------------
-// Front end (MFCC) -- one 64-lane workgroup handles MFCC_PAIRS frame pairs (2 real frames are packed
-// into one 512-point complex FFT).
+// Front end (MFCC) -- a workgroup of MFCC_WAVES wavefronts handles MFCC_FRAMES_PER_WG frames; each wavefront
+// transforms frame pairs (2 real frames are packed into one 512-point complex FFT).
 constexpr int NFFT = 512;
 constexpr int NBINS = NFFT / 2 + 1;       // 257
 constexpr int MEL_CHUNK = 8;              // bins per lane in the sparse mel stage
-constexpr int MFCC_PAIRS = 5;             // frame pairs per workgroup (10 frames)
+#ifndef KWS_MFCC_WAVES
+#define KWS_MFCC_WAVES 3
+#endif
+#ifndef KWS_MFCC_PAIRS_PER_WAVE
+#define KWS_MFCC_PAIRS_PER_WAVE 4
+#endif
+constexpr int MFCC_WAVES = KWS_MFCC_WAVES;             // wavefronts per workgroup
+constexpr int MFCC_THREADS = MFCC_WAVES * 64;
+constexpr int MFCC_FRAMES_PER_WG = 2 * KWS_MFCC_PAIRS_PER_WAVE * MFCC_WAVES;
 constexpr int MAX_NFILT = 64;
 constexpr int MAX_NUMCEP = 32;
 
@@ -29,8 +37,8 @@ struct FrontendParams {
     int numcep;
     int append_energy;
     float preemph;
-    int chunk_samples;     // samples staged per workgroup = (2*MFCC_PAIRS-1)*frame_step + frame_len
-    int vec_ok;            // 1 -> 16-byte vector loads of PCM are legal for every workgroup
+    int chunk_samples;     // samples staged per workgroup = (MFCC_FRAMES_PER_WG-1)*frame_step + frame_len
+    int vec_ok;            // 1 -> every workgroup's first sample is 16-byte aligned (vector PCM loads legal)
 };
 
 // Device tables of the front end (all float32 unless noted), built on the host in double.

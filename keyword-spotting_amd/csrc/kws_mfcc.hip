@@ -2,9 +2,14 @@
 // (reference call site kws/libs/audio_processor.py:270-278; stages a1-a8 of SURVEY.md section 8).
 //
 // Work decomposition
-//   grid  = (ceil(num_frames / (2*MFCC_PAIRS)), B); one 64-lane wavefront per workgroup.
-//   A workgroup stages the PCM span of its 10 frames (1840 samples for 400/160) from HBM with 16-byte
-//   loads, converts to float32, applies pre-emphasis once, and keeps the span in LDS.
+//   grid = (ceil(num_frames / 24), B); a workgroup is MFCC_WAVES (3) wavefronts and owns 24 frames
+//   (12 frame pairs, four per wavefront; shape chosen by A/B timing on MI355X).  Together
+//   the waves stage the PCM span of those frames (4080 samples for 400/160) from HBM with 16-byte loads,
+//   convert to float32, apply pre-emphasis once
+//   and keep the span in LDS, next to the tables every wave needs (DCT x lifter, sparse-mel weights,
+//   second-pass twiddles).  After one barrier the waves never synchronise again: each has a private
+//   5 KiB scratch and LDS instructions of one wavefront execute in order.
+//
 //   Two real frames are packed into one 512-point complex FFT (z = a + i*b): lane l holds
 //   z[64*n1 + l], n1 = 0..7, and the transform is three radix-8 passes in registers with two LDS
 //   exchanges (8 x 8 x 8).  The spectra of the two frames are separated with the conjugate-symmetry
@@ -16,13 +21,15 @@
 //
 // Numerics: PCM/32768 and pre-emphasis are bit-exact float32 as in the reference pipeline (separate
 // multiply and subtract roundings); everything after is float32 here vs float64 in psf
-// (tolerance 1e-4 on MFCC, see tests/test_mfcc_gpu.py).
+// (tolerance 1e-4 on MFCC, see tests/test_gpu_parity.py).
 #include "kws_internal.h"
 
 namespace kws {
 namespace {
 
-struct cf {
+// 8-byte aligned so the compiler moves a complex value with one ds_read_b64 / ds_write_b64 (an unaligned
+// pair becomes ds_read2_b32: twice the LDS cycles and the 32-bank conflict rules)
+struct alignas(8) cf {
     float x, y;
 };
 
@@ -64,9 +71,13 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
 // ds_read_b128 lane group fetches in the second exchange on sixteen different 16-byte slots.
 constexpr int XROW1 = 72, XROW2 = 66;
 
-// Every workgroup is ONE wavefront: LDS instructions of a wavefront execute in order, so data written by one
-// lane is visible to a later read of another lane without s_barrier or s_waitcnt; only the compiler has to
-// keep the order.
+// Per-wavefront LDS scratch (bytes): exchange / spectrum buffer, then the log-mel vectors.  The power
+// spectrum and the chunk partials reuse the exchange buffer once the spectrum has been read.
+constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_CBUF = 2112, SCR_LBUF = 4608, SCR_BYTES = 4608 + 512;
+
+// LDS instructions of one wavefront execute in order, so data written by one lane is visible to a later
+// read of another lane of the SAME wavefront without s_barrier or s_waitcnt; only the compiler has to keep
+// the order.
 __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -79,8 +90,9 @@ __device__ __forceinline__ int zswz(int k) { return k ^ ((k >> 3) & 7); }
 // 512-point complex FFT across one wavefront.
 //   in : lane l holds z[64*n1 + l] in v[n1]
 //   out: lane l (k1 = l>>3, c = l&7) holds Z[k1 + 8*c + 64*d] in v[d]
-// xbuf: 8*XROW1 complex of LDS private to the wavefront.
-__device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], const cf (&t2)[8], int lane) {
+// xbuf: 8*XROW1 complex of LDS private to the wavefront; t1[i] = W512^(lane*i); tw2 = LDS table [8][8] of
+// W64^(q*i).
+__device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], const cf* tw2, int lane) {
     const int k1 = lane >> 3, q = lane & 7;
     dft8(v);  // over n1 -> k1 (register index)
 #pragma unroll
@@ -94,7 +106,7 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
     wave_lds_order();
     dft8(v);  // over a -> c
 #pragma unroll
-    for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], t2[i]);  // W64^(b*c)
+    for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], tw2[q * 8 + i]);  // W64^(b*c)
 #pragma unroll
     for (int c = 0; c < 8; ++c) xbuf[k1 * XROW2 + 8 * c + q] = v[c];
     wave_lds_order();
@@ -105,26 +117,42 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
     dft8(v);  // over b -> d
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+// Full-wavefront sum without LDS: scan inside the 16-lane rows, fold the rows, broadcast lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift_add(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+    return v + o;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_shift_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_shift_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_shift_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_shift_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_shift_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v = dpp_shift_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// Load the per-lane FFT twiddles.
-__device__ __forceinline__ void load_twiddles(const float2* __restrict__ tw, int lane, cf (&t1)[8], cf (&t2)[8]) {
-    const int q = lane & 7;
+// First-pass twiddles of this lane, W512^(lane*i).
+__device__ __forceinline__ void load_twiddles(const float2* __restrict__ tw, int lane, cf (&t1)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        float2 a = tw[(lane * i) & 511];
-        float2 b = tw[(8 * q * i) & 511];
+        const float2 a = tw[(lane * i) & 511];
         t1[i] = {a.x, a.y};
-        t2[i] = {b.x, b.y};
+    }
+}
+// Second-pass twiddle table W64^(q*i) = W512^(8*q*i), [8][8] complex, into LDS (64 threads fill it).
+__device__ __forceinline__ void fill_tw2(const float2* __restrict__ tw, cf* tw2, int idx) {
+    if (idx < 64) {
+        const float2 a = tw[(8 * (idx >> 3) * (idx & 7)) & 511];
+        tw2[idx] = {a.x, a.y};
     }
 }
 
-// Write Z to LDS in natural order and return, for the bins this lane owns (k = lane + 64*j, j<4, and
-// k = 256 on lane 0), the power spectra 1/512*|A|^2, 1/512*|B|^2 of the two packed real frames.
+// Separate the two real spectra packed in Z and write, for every bin 0..256, the pair
+// (1/512*|A|^2, 1/512*|B|^2) (or the magnitudes) to pbuf, which ALIASES zbuf: all reads of the spectrum
+// are issued before the first write (LDS executes a wavefront's instructions in order).  Returns this
+// lane's share of the two frame energies.
 // nza / nzb: whether frame a / b has any non-zero sample.  An all-zero frame must give exactly 0 (the
 // reference then floors to eps); computed through the packed transform it would instead pick up the
 // partner frame's float32 rounding noise (-140 dB), so it is forced.
@@ -134,16 +162,21 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
 #pragma unroll
     for (int d = 0; d < 8; ++d) zbuf[zswz(k1 + 8 * q + 64 * d)] = v[d];
     wave_lds_order();
+    cf z[4], w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        z[j] = zbuf[zswz(k)];
+        w[j] = zbuf[zswz((NFFT - k) & (NFFT - 1))];
+    }
+    wave_lds_order();
+    const float scale = power ? (1.0f / (4.0f * NFFT)) : 0.25f;
     ea = 0.f;
     eb = 0.f;
-    const float scale = power ? (1.0f / (4.0f * NFFT)) : 0.25f;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int k = (j < 4) ? lane + 64 * j : 256;
-        if (j == 4 && lane != 0) break;
-        cf z = zbuf[zswz(k)], w = zbuf[zswz((NFFT - k) & (NFFT - 1))];
-        float ar = z.x + w.x, ai = z.y - w.y;  // 2*A
-        float br = z.y + w.y, bi = z.x - w.x;  // 2*B (up to a unit factor)
+    for (int j = 0; j < 4; ++j) {
+        const float ar = z[j].x + w[j].x, ai = z[j].y - w[j].y;  // 2*A
+        const float br = z[j].y + w[j].y, bi = z[j].x - w[j].x;  // 2*B (up to a unit factor)
         float pa = fmaf(ar, ar, ai * ai) * scale;
         float pb = fmaf(br, br, bi * bi) * scale;
         if (!power) {
@@ -152,7 +185,20 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         }
         pa = nza ? pa : 0.f;
         pb = nzb ? pb : 0.f;
-        pbuf[k] = make_float2(pa, pb);
+        pbuf[lane + 64 * j] = make_float2(pa, pb);
+        ea += pa;
+        eb += pb;
+    }
+    // bin 256 = Z[256] lives in lane 0, register 4 (k1 = 0, q = 0, d = 4); it is its own mirror image
+    if (lane == 0) {
+        float pa = (2.f * v[4].x) * (2.f * v[4].x) * scale, pb = (2.f * v[4].y) * (2.f * v[4].y) * scale;
+        if (!power) {
+            pa = sqrtf(pa);
+            pb = sqrtf(pb);
+        }
+        pa = nza ? pa : 0.f;
+        pb = nzb ? pb : 0.f;
+        pbuf[256] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
     }
@@ -161,82 +207,86 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
 
 constexpr float PSF_EPS = 2.220446049250313e-16f;  // numpy.finfo(float).eps, exactly 2^-52
 
-// ------------------------------------------------------------------------------------------------
 // Sample -> float32 in [-1, 1): int16 PCM is scaled like librosa/soundfile do (x / 32768, exact);
 // float32 input is taken as is (a signal the caller already decoded / augmented).
 __device__ __forceinline__ float to_unit(int16_t s) { return (float)s * (1.0f / 32768.0f); }
 __device__ __forceinline__ float to_unit(float s) { return s; }
 
+// ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const FrontendTables& t, const T* __restrict__ wav,
                                           float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // carve (all offsets multiples of 16 bytes)
-    cf* xbuf = reinterpret_cast<cf*>(smem);                                  // 8*72 complex = 4608 B
-    float2* pbuf = reinterpret_cast<float2*>(smem + 4608);                   // 264 float2 = 2112 B
-    float* lbuf = reinterpret_cast<float*>(smem + 4608 + 2112);              // 2*64 floats = 512 B
-    float* dctb = reinterpret_cast<float*>(smem + 4608 + 2112 + 512);        // numcep*nfilt (<= 2048 floats)
-    const int dct_n = p.numcep * p.nfilt;
-    float* ybuf = dctb + ((dct_n + 3) & ~3);                                 // chunk_samples floats
+    // workgroup-shared part (every offset a multiple of 16 bytes)
+    const int nfp = (p.nfilt + 3) & ~3;                        // DCT rows padded to float4
+    float* dctb = reinterpret_cast<float*>(smem);              // [numcep][nfp]
+    float* melw = dctb + p.numcep * nfp;                       // [16][64]: rw[0..7], fw[0..7] per lane
+    cf* tw2 = reinterpret_cast<cf*>(melw + 16 * 64);           // [8][8]
+    float* ybuf = reinterpret_cast<float*>(tw2 + 64);          // chunk_samples floats (padded to 8)
+    unsigned char* scr0 = reinterpret_cast<unsigned char*>(ybuf + ((p.chunk_samples + 7) & ~7));
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int clip = blockIdx.y;
-    const int f0 = blockIdx.x * (2 * MFCC_PAIRS);
+    const int f0 = blockIdx.x * MFCC_FRAMES_PER_WG;
     const T* __restrict__ x = wav + (size_t)clip * p.n_samples;
 
-    // ---- stage PCM span -> float32, pre-emphasised, in LDS ---------------------------------------
+    // ---- stage PCM span -> float32, pre-emphasised, in LDS; shared tables -------------------------
     const int s0 = f0 * p.frame_step;
     const float c = p.preemph;
-    if (sizeof(T) == 2 && p.vec_ok && s0 + p.chunk_samples <= p.n_samples) {
-        // chunk_samples is a multiple of 8 here and every 8-sample group is 16-byte aligned
-        for (int g = lane; g * 8 < p.chunk_samples; g += 64) {
-            const int n = s0 + g * 8;
+    for (int g = tid; g * 8 < p.chunk_samples; g += MFCC_THREADS) {
+        const int n = s0 + g * 8;
+        float y[8];
+        if (sizeof(T) == 2 && p.vec_ok && n + 8 <= p.n_samples) {
+            // every 8-sample group is 16-byte aligned here
             const uint4 raw = *reinterpret_cast<const uint4*>(x + n);
             float prev = (n > 0) ? to_unit(x[n - 1]) : 0.f;
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-            float y[8];
+            const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int16_t s = (int16_t)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                const int16_t s = (int16_t)((wd[i >> 1] >> (16 * (i & 1))) & 0xffffu);
                 const float cur = to_unit(s);
                 y[i] = (n + i > 0) ? __fsub_rn(cur, __fmul_rn(c, prev)) : cur;
                 prev = cur;
             }
-            float4* dst = reinterpret_cast<float4*>(ybuf + g * 8);
-            dst[0] = make_float4(y[0], y[1], y[2], y[3]);
-            dst[1] = make_float4(y[4], y[5], y[6], y[7]);
-        }
-    } else {
-        for (int i = lane; i < p.chunk_samples; i += 64) {
-            const int n = s0 + i;
-            float y = 0.f;
-            if (n < p.n_samples) {
-                const float cur = to_unit(x[n]);
-                y = (n > 0) ? __fsub_rn(cur, __fmul_rn(c, to_unit(x[n - 1]))) : cur;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = n + i;
+                float v = 0.f;
+                if (m < p.n_samples) {
+                    const float cur = to_unit(x[m]);
+                    v = (m > 0) ? __fsub_rn(cur, __fmul_rn(c, to_unit(x[m - 1]))) : cur;
+                }
+                y[i] = v;
             }
-            ybuf[i] = y;
         }
+        float4* dst = reinterpret_cast<float4*>(ybuf + g * 8);
+        dst[0] = make_float4(y[0], y[1], y[2], y[3]);
+        dst[1] = make_float4(y[4], y[5], y[6], y[7]);
     }
-    for (int i = lane; i < dct_n; i += 64) dctb[i] = t.dct[i];
+    for (int i = tid; i < p.numcep * nfp; i += MFCC_THREADS) {
+        const int r = i / nfp, j = i % nfp;
+        dctb[i] = j < p.nfilt ? t.dct[r * p.nfilt + j] : 0.f;
+    }
+    for (int i = tid; i < 16 * 64; i += MFCC_THREADS) melw[i] = i < 8 * 64 ? t.mel_rw[i] : t.mel_fw[i - 8 * 64];
+    fill_tw2(t.twiddle, tw2, tid);
 
     // ---- per-lane constants -----------------------------------------------------------------------
-    cf t1[8], t2[8];
-    load_twiddles(t.twiddle, lane, t1, t2);
+    cf t1[8];
+    load_twiddles(t.twiddle, lane, t1);
     const int mk0 = t.mel_k0[lane];
-    float rw[MEL_CHUNK], fw[MEL_CHUNK];
-#pragma unroll
-    for (int i = 0; i < MEL_CHUNK; ++i) {
-        rw[i] = t.mel_rw[i * 64 + lane];
-        fw[i] = t.mel_fw[i * 64 + lane];
-    }
     const uint32_t gth = t.mel_gather[lane];
-    wave_lds_order();
+    __syncthreads();  // the only workgroup barrier: staged samples and tables are visible to all waves
 
-    float4* cbuf = reinterpret_cast<float4*>(xbuf);  // 64 float4 chunk partials (aliases the exchange buffer)
+    unsigned char* scr = scr0 + wv * SCR_BYTES;
+    cf* xbuf = reinterpret_cast<cf*>(scr + SCR_XBUF);
+    float2* pbuf = reinterpret_cast<float2*>(scr + SCR_PBUF);
+    float4* cbuf = reinterpret_cast<float4*>(scr + SCR_CBUF);
+    float* lbuf = reinterpret_cast<float*>(scr + SCR_LBUF);
 
-    for (int pr = 0; pr < MFCC_PAIRS; ++pr) {
+    for (int pr = wv; pr < MFCC_FRAMES_PER_WG / 2; pr += MFCC_WAVES) {
         const int fa = f0 + 2 * pr;
-        if (fa >= p.num_frames) break;  // uniform
+        if (fa >= p.num_frames) break;  // wave-uniform
         const bool has_b = (fa + 1) < p.num_frames;
         const float* ya = ybuf + (2 * pr) * p.frame_step;
         const float* yb = ya + p.frame_step;
@@ -254,7 +304,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         }
         nza = __any(nza);
         nzb = __any(nzb);
-        fft512(v, xbuf, t1, t2, lane);
+        fft512(v, xbuf, t1, tw2, lane);
 
         float ea, eb;
         split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ea, eb);
@@ -267,13 +317,16 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         for (int i = 0; i < MEL_CHUNK; ++i) {
             const int k = min(mk0 + i, NBINS - 1);
             const float2 pw = pbuf[k];
-            ra = fmaf(rw[i], pw.x, ra);
-            fa_ = fmaf(fw[i], pw.x, fa_);
-            rb = fmaf(rw[i], pw.y, rb);
-            fb_ = fmaf(fw[i], pw.y, fb_);
+            const float rwi = melw[i * 64 + lane], fwi = melw[(8 + i) * 64 + lane];
+            ra = fmaf(rwi, pw.x, ra);
+            fa_ = fmaf(fwi, pw.x, fa_);
+            rb = fmaf(rwi, pw.y, rb);
+            fb_ = fmaf(fwi, pw.y, fb_);
         }
+        wave_lds_order();
         cbuf[lane] = make_float4(ra, fa_, rb, fb_);
         wave_lds_order();
+        float la = 0.f, lb = 0.f;
         if (lane < p.nfilt) {
             const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
             float sa = 0.f, sb = 0.f;
@@ -287,29 +340,39 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
                 sa += qv.y;
                 sb += qv.w;
             }
-            lbuf[lane] = logf(sa == 0.f ? PSF_EPS : sa);
-            lbuf[64 + lane] = logf(sb == 0.f ? PSF_EPS : sb);
+            la = logf(sa == 0.f ? PSF_EPS : sa);
+            lb = logf(sb == 0.f ? PSF_EPS : sb);
         }
+        // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
+        // table-rounding error a -36 log-floor would otherwise amplify.
+        const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
+        const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
+        lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
+        lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
         wave_lds_order();
 
         // DCT-II(ortho) x lifter: lane -> (frame f = lane>>5, coefficient i = lane&31)
         {
             const int f = lane >> 5, i = lane & 31;
             if (i < p.numcep && (f == 0 || has_b)) {
-                const float* L = lbuf + 64 * f;
-                const float* D = dctb + i * p.nfilt;
-                const float m = L[0];
-                float acc = 0.f, dsum = 0.f;
-                for (int j = 0; j < p.nfilt; ++j) {
-                    acc = fmaf(D[j], L[j] - m, acc);
-                    dsum += D[j];
+                const float4* L4 = reinterpret_cast<const float4*>(lbuf + 64 * f);
+                const float4* D4 = reinterpret_cast<const float4*>(dctb + i * nfp);
+                float acc = 0.f;
+                for (int j = 0; j < nfp / 4; ++j) {
+                    const float4 d = D4[j], l = L4[j];
+                    acc = fmaf(d.x, l.x, acc);
+                    acc = fmaf(d.y, l.y, acc);
+                    acc = fmaf(d.z, l.z, acc);
+                    acc = fmaf(d.w, l.w, acc);
                 }
                 if (i == 0) {
                     if (p.append_energy) {
                         const float e = f ? eb : ea;
                         acc = logf(e == 0.f ? PSF_EPS : e);
                     } else {
-                        acc = fmaf(m, dsum, acc);
+                        float dsum = 0.f;
+                        for (int j = 0; j < p.nfilt; ++j) dsum += dctb[j];
+                        acc = fmaf(f ? mb : ma, dsum, acc);
                     }
                 }
                 out[((size_t)clip * p.num_frames + (fa + f)) * p.numcep + i] = acc;
@@ -319,12 +382,14 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     }
 }
 
-__global__ __launch_bounds__(64) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
-                                                          const int16_t* __restrict__ wav, float* __restrict__ out) {
+__global__ __launch_bounds__(MFCC_THREADS) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
+                                                                    const int16_t* __restrict__ wav,
+                                                                    float* __restrict__ out) {
     mfcc_body<int16_t>(p, t, wav, out);
 }
-__global__ __launch_bounds__(64) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
-                                                          const float* __restrict__ wav, float* __restrict__ out) {
+__global__ __launch_bounds__(MFCC_THREADS) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
+                                                                    const float* __restrict__ wav,
+                                                                    float* __restrict__ out) {
     mfcc_body<float>(p, t, wav, out);
 }
 
@@ -352,14 +417,17 @@ __global__ void kws_framesig_f32_kernel(const float* __restrict__ in, int n, int
 __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, const float* __restrict__ frames,
                                                              int num_frames, int frame_len, int power,
                                                              float* __restrict__ spec) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4608 + 2112];
-    cf* xbuf = reinterpret_cast<cf*>(smem);
-    float2* pbuf = reinterpret_cast<float2*>(smem + 4608);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SCR_BYTES + 512];
+    cf* xbuf = reinterpret_cast<cf*>(smem + SCR_XBUF);
+    float2* pbuf = reinterpret_cast<float2*>(smem + SCR_PBUF);
+    cf* tw2 = reinterpret_cast<cf*>(smem + SCR_BYTES);
     const int lane = threadIdx.x;
     const int fa = 2 * blockIdx.x;
     const bool has_b = fa + 1 < num_frames;
-    cf t1[8], t2[8];
-    load_twiddles(t.twiddle, lane, t1, t2);
+    cf t1[8];
+    load_twiddles(t.twiddle, lane, t1);
+    fill_tw2(t.twiddle, tw2, lane);
+    wave_lds_order();
     const float* ya = frames + (size_t)fa * frame_len;
     const float* yb = ya + frame_len;
     cf v[8];
@@ -375,7 +443,7 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
     }
     nza = __any(nza);
     nzb = __any(nzb);
-    fft512(v, xbuf, t1, t2, lane);
+    fft512(v, xbuf, t1, tw2, lane);
     float ea, eb;
     split_power(v, xbuf, pbuf, lane, power, nza, nzb, ea, eb);
     for (int k = lane; k < NBINS; k += 64) {
@@ -388,18 +456,22 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+size_t mfcc_lds_bytes(const FrontendParams& p) {
+    const int nfp = (p.nfilt + 3) & ~3;
+    return sizeof(float) * (size_t)(p.numcep * nfp + 16 * 64 + 2 * 64 + ((p.chunk_samples + 7) & ~7)) +
+           (size_t)MFCC_WAVES * SCR_BYTES;
+}
+
 template <typename T, typename K>
 static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p, const FrontendTables& t, const T* d_wav,
                                 int B, float* d_out) {
-    const int per_wg = 2 * MFCC_PAIRS;
-    dim3 grid((p.num_frames + per_wg - 1) / per_wg, B);
-    const int dct_n = p.numcep * p.nfilt;
-    const size_t lds = 4608 + 2112 + 512 + sizeof(float) * (size_t)(((dct_n + 3) & ~3) + ((p.chunk_samples + 3) & ~3));
+    dim3 grid((p.num_frames + MFCC_FRAMES_PER_WG - 1) / MFCC_FRAMES_PER_WG, B);
+    const size_t lds = mfcc_lds_bytes(p);
     // grid.y is limited to 65535: split very large batches
     for (int b0 = 0; b0 < B; b0 += 65535) {
         const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
         grid.y = nb;
-        hipLaunchKernelGGL(kernel, grid, dim3(64), lds, s, p, t, d_wav + (size_t)b0 * p.n_samples,
+        hipLaunchKernelGGL(kernel, grid, dim3(MFCC_THREADS), lds, s, p, t, d_wav + (size_t)b0 * p.n_samples,
                            d_out + (size_t)b0 * p.num_frames * p.numcep);
     }
     return hipGetLastError();
