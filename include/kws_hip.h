@@ -121,6 +121,34 @@ int kws_reserve(kws_ctx* ctx, int max_batch);
 int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label,
                           float* d_act, int use_mfma);
 
+/* ---- streaming: 10 ms hops over concurrent streams (BASELINE.json config 5) ------------------------ */
+
+/* The reference's streaming use case is VAD-segmented capture followed by one whole-clip inference
+ * (kws/inference/inference_local.py:114-192).  Here every push of frame_step (160) new samples per stream
+ * completes one MFCC frame per stream (frames of the continuous signal: frame f = samples
+ * [160 f, 160 f + 400)), appends it to a ring of num_frames (99) frames, and classifies the last 99 frames
+ * (one second) of every stream.  Until a stream has produced 99 frames the missing rows are zeros. */
+int kws_stream_open(kws_ctx* ctx, int n_streams);
+int kws_stream_close(kws_ctx* ctx);
+/* d_hop: int16 [n_streams, frame_step] new samples; d_logits float32 [n_streams, C] (NULL: features only);
+ * d_label int32 [n_streams] or NULL.  use_graph != 0 replays the three launches of a push (frame kernel,
+ * hop counter, DS-CNN) as one hipGraph (built on first use for the given pointer triple). */
+int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
+/* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
+ * by the context) and the number of pushes so far; the newest frame is row (hops - 3) mod num_frames. */
+int kws_stream_state(kws_ctx* ctx, const float** d_feat_ring, int* hops);
+/* Copy the raw feature ring (float32 [n_streams, num_frames, numcep], ring order) into caller memory. */
+int kws_stream_copy_features(kws_ctx* ctx, float* d_out);
+
+/* ---- augmentation of the training transform (kws/libs/audio_processor.py:151-159,172-233) ---------- */
+
+/* out[b][i] = (silence[b] ? 0 : wav[b][i - shift[b]] / 32768, 0 outside the clip) + bg_vol[b] * bg[bg_off[b] + i]
+ * as float32 [B, n_samples], ready for kws_mfcc_f32.  d_shift int32 [B] (NULL: no shift), d_bg float32
+ * [bg_len] background pool (NULL: no mix) with per-clip offsets int32 [B] and volumes float32 [B],
+ * d_silence uint8 [B] (NULL: none).  The random draws stay with the caller (host), as in the reference. */
+int kws_augment_i16(kws_ctx* ctx, const int16_t* d_wav, int B, const int32_t* d_shift, const float* d_bg, int bg_len,
+                    const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence, float* d_out);
+
 /* Diagnostics: the same forward with per-clip shader-clock stamps (s_memtime of thread 0) at the phase
  * boundaries of the DS-CNN kernel, uint64 [B, KWS_DSCNN_STAMPS]: 0 start, 1 features staged, 2/3 conv1
  * done / barrier, 4/5 .. 10/11 blocks 1..4 done / barrier, 12 end; [14], [15] = 100 MHz real-time

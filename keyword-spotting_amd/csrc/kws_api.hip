@@ -131,6 +131,14 @@ struct kws_ctx {
     float* d_feat_ws = nullptr;
     size_t feat_ws_floats = 0;
 
+    // streaming state (kws_stream_*): per-stream PCM ring, feature ring, hop counter, optional graph
+    int n_streams = 0, ring_len = 0;
+    int16_t* d_pcm_ring = nullptr;
+    float* d_feat_ring = nullptr;
+    int* d_hops = nullptr;
+    hipGraphExec_t stream_graph = nullptr;
+    const void* graph_key[3] = {nullptr, nullptr, nullptr};
+
     // profiling
     bool prof = false;
     struct EvPair {
@@ -186,6 +194,8 @@ struct ProfScope {
     }
 };
 
+static void stream_free_fwd(kws_ctx* c);
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -238,6 +248,10 @@ void kws_destroy(kws_ctx* c) {
     if (c->d_fe) (void)hipFree(c->d_fe);
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
+    if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
+    if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
+    if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
+    if (c->d_hops) (void)hipFree(c->d_hops);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -287,6 +301,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
+    if (c->n_streams) stream_free_fwd(c);         // ring geometry depends on the front end
     void* d = nullptr;
     if (hipMalloc(&d, total) != hipSuccess) return fail(c, KWS_ENOMEM, "kws_set_frontend: device allocation failed");
     hipError_t e = hipMemcpy(d, host.data(), total, hipMemcpyHostToDevice);
@@ -478,6 +493,129 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, 1, "kws_infer_i16");
 }
 
+// ---- streaming ------------------------------------------------------------------------------------
+static void stream_free(kws_ctx* c) {
+    if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
+    if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
+    if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
+    if (c->d_hops) (void)hipFree(c->d_hops);
+    c->stream_graph = nullptr;
+    c->d_pcm_ring = nullptr;
+    c->d_feat_ring = nullptr;
+    c->d_hops = nullptr;
+    c->n_streams = 0;
+}
+
+int kws_stream_open(kws_ctx* c, int n_streams) {
+    if (!c) return KWS_EINVAL;
+    if (n_streams <= 0) return fail(c, KWS_EINVAL, "kws_stream_open: n_streams must be positive");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_stream_open: front end not configured");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    stream_free(c);
+    const FrontendParams& p = c->fp;
+    c->ring_len = ((p.frame_len + p.frame_step - 1) / p.frame_step + 1) * p.frame_step;
+    const size_t pcm_b = sizeof(int16_t) * (size_t)n_streams * c->ring_len;
+    const size_t feat_b = sizeof(float) * (size_t)n_streams * p.num_frames * p.numcep;
+    if (hipMalloc(reinterpret_cast<void**>(&c->d_pcm_ring), pcm_b) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_feat_ring), feat_b) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_hops), sizeof(int)) != hipSuccess) {
+        stream_free(c);
+        return fail(c, KWS_ENOMEM, "kws_stream_open: device allocation failed");
+    }
+    c->n_streams = n_streams;
+    HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, sizeof(int), c->stream));
+    return KWS_OK;
+}
+
+int kws_stream_close(kws_ctx* c) {
+    if (!c) return KWS_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    stream_free(c);
+    return KWS_OK;
+}
+
+static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label) {
+    hipError_t e = launch_stream_frame(c->stream, c->fp, c->ft, d_hop, c->n_streams, c->d_pcm_ring, c->ring_len,
+                                       c->d_feat_ring, c->d_hops);
+    if (e != hipSuccess) return e;
+    e = launch_stream_tick(c->stream, c->d_hops);
+    if (e != hipSuccess) return e;
+    if (d_logits)
+        e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, 1, nullptr, c->d_hops);
+    return e;
+}
+
+int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_push_i16: call kws_stream_open first");
+    if (!d_hop) return fail(c, KWS_EINVAL, "kws_stream_push_i16: d_hop is NULL");
+    if (d_logits) {
+        if (!c->model_ready) return fail(c, KWS_ESTATE, "kws_stream_push_i16: no model loaded (kws_load_dscnn)");
+        if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
+            return fail(c, KWS_EUNSUPPORTED, "kws_stream_push_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (use_graph) {
+        // one hipGraph per (hop, logits, label) pointer triple: the three launches replay as one submission
+        if (!c->stream_graph || c->graph_key[0] != d_hop || c->graph_key[1] != d_logits || c->graph_key[2] != d_label) {
+            if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
+            c->stream_graph = nullptr;
+            hipGraph_t g = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t e = stream_enqueue(c, d_hop, d_logits, d_label);
+            hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+            if (e != hipSuccess || e2 != hipSuccess || !g) return fail_hip(c, e != hipSuccess ? e : e2, "kws_stream_push_i16: graph capture");
+            e = hipGraphInstantiate(&c->stream_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail_hip(c, e, "kws_stream_push_i16: hipGraphInstantiate");
+            c->graph_key[0] = d_hop;
+            c->graph_key[1] = d_logits;
+            c->graph_key[2] = d_label;
+        }
+        HIP_TRY(c, hipGraphLaunch(c->stream_graph, c->stream));
+        return KWS_OK;
+    }
+    HIP_TRY(c, stream_enqueue(c, d_hop, d_logits, d_label));
+    return KWS_OK;
+}
+
+int kws_stream_state(kws_ctx* c, const float** d_feat_ring, int* hops) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_state: no open stream set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_feat_ring) *d_feat_ring = c->d_feat_ring;
+    if (hops) HIP_TRY(c, hipMemcpy(hops, c->d_hops, sizeof(int), hipMemcpyDeviceToHost));
+    return KWS_OK;
+}
+
+int kws_stream_copy_features(kws_ctx* c, float* d_out) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_copy_features: no open stream set");
+    if (!d_out) return fail(c, KWS_EINVAL, "kws_stream_copy_features: d_out is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(d_out, c->d_feat_ring, sizeof(float) * (size_t)c->n_streams * c->fp.num_frames * c->fp.numcep,
+                              hipMemcpyDeviceToDevice, c->stream));
+    return KWS_OK;
+}
+
+// ---- augmentation ---------------------------------------------------------------------------------
+int kws_augment_i16(kws_ctx* c, const int16_t* d_wav, int B, const int32_t* d_shift, const float* d_bg, int bg_len,
+                    const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence, float* d_out) {
+    int rc = check_batch(c, d_wav, B, "kws_augment_i16");
+    if (rc) return rc;
+    if (!d_out) return fail(c, KWS_EINVAL, "kws_augment_i16: d_out is NULL");
+    if (d_bg && (bg_len <= 0 || !d_bg_off || !d_bg_vol)) return fail(c, KWS_EINVAL, "kws_augment_i16: background pool needs length, offsets and volumes");
+    if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_augment_i16: front end not configured");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_augment(c->stream, d_wav, B, c->fp.n_samples, d_shift, d_bg, bg_len, d_bg_off, d_bg_vol, d_silence, d_out));
+    return KWS_OK;
+}
+
 // ---- sigproc operators --------------------------------------------------------------------------
 int kws_preemphasis_f32(kws_ctx* c, const float* d_signal, int n, float coeff, float* d_out) {
     int rc = check_batch(c, d_signal, n, "kws_preemphasis_f32");
@@ -596,3 +734,5 @@ int kws_host_dct_lifter(int nfilt, int numcep, int ceplifter, float* out) {
 
 }  // extern "C"
 #pragma GCC visibility pop
+
+static void stream_free_fwd(kws_ctx* c) { stream_free(c); }

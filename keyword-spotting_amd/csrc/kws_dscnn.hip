@@ -392,7 +392,8 @@ template <int MODE>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
                                                            float* __restrict__ act,
-                                                           unsigned long long* __restrict__ stamps) {
+                                                           unsigned long long* __restrict__ stamps,
+                                                           const int* __restrict__ ring_hops) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool MFMA = MODE != 0;
     const int tid = threadIdx.x;
@@ -425,8 +426,14 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     const float* f = feat + (size_t)clip * (IN_T * IN_F);
     constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
     float fv[FV];
+    // streaming: the feature map is a ring of IN_T frames; after `hops` pushes the newest frame sits in row
+    // (hops - 3) mod IN_T and the window starts one row after it
+    const int head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
 #pragma unroll
-    for (int k = 0; k < FV; ++k) fv[k] = (tid + k * NT) < IN_T * IN_F ? f[tid + k * NT] : 0.f;
+    for (int k = 0; k < FV; ++k) {
+        const int i = tid + k * NT;
+        fv[k] = i < IN_T * IN_F ? f[((i / IN_F + head) % IN_T) * IN_F + i % IN_F] : 0.f;
+    }
     for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
     {
         BlockTables t1;
@@ -547,16 +554,16 @@ hipError_t dscnn_init_device() {
 }
 
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
-                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps) {
+                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps, const int* d_ring_hops) {
     const size_t lds = LDS_FLOATS * sizeof(float);
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
     // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /
     // stencil only; wrong results by construction, reachable only through the diagnostics entry point)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
-        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
-        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
-        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps); break;
+        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
     }
     return hipGetLastError();
 }

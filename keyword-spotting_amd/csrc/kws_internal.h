@@ -67,6 +67,15 @@ hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTab
                        const int16_t* d_wav, int B, float* d_out);
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t,
                            const float* d_wav, int B, float* d_out);
+size_t mfcc_lds_bytes(const FrontendParams& p);
+// Streaming: one hop of frame_step new samples per stream -> one new MFCC frame per stream in the feature ring.
+hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, const int* d_hops);
+hipError_t launch_stream_tick(hipStream_t s, int* d_hops);
+// Training-time augmentation on the device (time shift, silence, background mix).
+hipError_t launch_augment(hipStream_t s, const int16_t* d_wav, int B, int n, const int32_t* d_shift, const float* d_bg,
+                          int bg_len, const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence,
+                          float* d_out);
 hipError_t launch_preemphasis(hipStream_t s, const float* d_in, int n, float coeff, float* d_out);
 hipError_t launch_framesig(hipStream_t s, const float* d_in, int n, int frame_len, int frame_step,
                            int num_frames, const float* d_window, float* d_frames);
@@ -95,7 +104,8 @@ struct DscnnWeights {
 
 hipError_t dscnn_init_device();
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
-                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr);
+                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
+                        const int* d_ring_hops = nullptr);
 
 extern const char* const kKernelNames[KWS_K_COUNT];
 

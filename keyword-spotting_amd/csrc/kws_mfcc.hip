@@ -212,6 +212,109 @@ constexpr float PSF_EPS = 2.220446049250313e-16f;  // numpy.finfo(float).eps, ex
 __device__ __forceinline__ float to_unit(int16_t s) { return (float)s * (1.0f / 32768.0f); }
 __device__ __forceinline__ float to_unit(float s) { return s; }
 
+// Views of the LDS a wavefront needs for one frame pair: its private scratch and the workgroup tables.
+struct PairScratch {
+    cf* xbuf;          // 8*XROW1 complex: exchange buffer / spectrum / power spectrum
+    float2* pbuf;      // aliases xbuf
+    float4* cbuf;      // chunk partials
+    float* lbuf;       // 2 x 64 centred log-mel values
+    const float* dctb; // [numcep][nfp]
+    const float* melw; // [16][64]
+    const cf* tw2;     // [8][8]
+    int nfp;
+};
+
+// One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
+// FFT -> split -> power -> sparse mel -> log -> DCT x lifter, c0 = log(frame energy).
+// out_a / out_b: rows of numcep floats for frame a / b (out_b is not touched when has_b is false).
+__device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
+                                          const PairScratch& sc, const cf (&t1)[8], int mk0, uint32_t gth, int lane,
+                                          float* __restrict__ out_a, float* __restrict__ out_b) {
+    cf* xbuf = sc.xbuf;
+    float2* pbuf = sc.pbuf;
+    float4* cbuf = sc.cbuf;
+    float* lbuf = sc.lbuf;
+    const float* dctb = sc.dctb;
+    const float* melw = sc.melw;
+    const cf* tw2 = sc.tw2;
+    const int nfp = sc.nfp;
+    fft512(v, xbuf, t1, tw2, lane);
+
+    float ea, eb;
+    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ea, eb);
+    ea = wave_sum(ea);
+    eb = wave_sum(eb);
+
+    // sparse mel: this lane's chunk of <= 8 bins
+    float ra = 0.f, fa_ = 0.f, rb = 0.f, fb_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < MEL_CHUNK; ++i) {
+        const int k = min(mk0 + i, NBINS - 1);
+        const float2 pw = pbuf[k];
+        const float rwi = melw[i * 64 + lane], fwi = melw[(8 + i) * 64 + lane];
+        ra = fmaf(rwi, pw.x, ra);
+        fa_ = fmaf(fwi, pw.x, fa_);
+        rb = fmaf(rwi, pw.y, rb);
+        fb_ = fmaf(fwi, pw.y, fb_);
+    }
+    wave_lds_order();
+    cbuf[lane] = make_float4(ra, fa_, rb, fb_);
+    wave_lds_order();
+    float la = 0.f, lb = 0.f;
+    if (lane < p.nfilt) {
+        const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
+        float sa = 0.f, sb = 0.f;
+        for (int i = 0; i < nr; ++i) {
+            const float4 qv = cbuf[r0 + i];
+            sa += qv.x;
+            sb += qv.z;
+        }
+        for (int i = 0; i < nq; ++i) {
+            const float4 qv = cbuf[q0 + i];
+            sa += qv.y;
+            sb += qv.w;
+        }
+        la = logf(sa == 0.f ? PSF_EPS : sa);
+        lb = logf(sb == 0.f ? PSF_EPS : sb);
+    }
+    // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
+    // table-rounding error a -36 log-floor would otherwise amplify.
+    const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
+    const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
+    lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
+    lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
+    wave_lds_order();
+
+    // DCT-II(ortho) x lifter: lane -> (frame f = lane>>5, coefficient i = lane&31)
+    {
+        const int f = lane >> 5, i = lane & 31;
+        if (i < p.numcep && (f == 0 || has_b)) {
+            const float4* L4 = reinterpret_cast<const float4*>(lbuf + 64 * f);
+            const float4* D4 = reinterpret_cast<const float4*>(dctb + i * nfp);
+            float acc = 0.f;
+            for (int j = 0; j < nfp / 4; ++j) {
+                const float4 d = D4[j], l = L4[j];
+                acc = fmaf(d.x, l.x, acc);
+                acc = fmaf(d.y, l.y, acc);
+                acc = fmaf(d.z, l.z, acc);
+                acc = fmaf(d.w, l.w, acc);
+            }
+            if (i == 0) {
+                if (p.append_energy) {
+                    const float e = f ? eb : ea;
+                    acc = logf(e == 0.f ? PSF_EPS : e);
+                } else {
+                    float dsum = 0.f;
+                    for (int j = 0; j < p.nfilt; ++j) dsum += dctb[j];
+                    acc = fmaf(f ? mb : ma, dsum, acc);
+                }
+            }
+            (f ? out_b : out_a)[i] = acc;
+        }
+    }
+    wave_lds_order();
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const FrontendTables& t, const T* __restrict__ wav,
@@ -279,10 +382,9 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     __syncthreads();  // the only workgroup barrier: staged samples and tables are visible to all waves
 
     unsigned char* scr = scr0 + wv * SCR_BYTES;
-    cf* xbuf = reinterpret_cast<cf*>(scr + SCR_XBUF);
-    float2* pbuf = reinterpret_cast<float2*>(scr + SCR_PBUF);
-    float4* cbuf = reinterpret_cast<float4*>(scr + SCR_CBUF);
-    float* lbuf = reinterpret_cast<float*>(scr + SCR_LBUF);
+    const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
+                            reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
+                            dctb, melw, tw2, nfp};
 
     for (int pr = wv; pr < MFCC_FRAMES_PER_WG / 2; pr += MFCC_WAVES) {
         const int fa = f0 + 2 * pr;
@@ -304,80 +406,9 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         }
         nza = __any(nza);
         nzb = __any(nzb);
-        fft512(v, xbuf, t1, tw2, lane);
-
-        float ea, eb;
-        split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ea, eb);
-        ea = wave_sum(ea);
-        eb = wave_sum(eb);
-
-        // sparse mel: this lane's chunk of <= 8 bins
-        float ra = 0.f, fa_ = 0.f, rb = 0.f, fb_ = 0.f;
-#pragma unroll
-        for (int i = 0; i < MEL_CHUNK; ++i) {
-            const int k = min(mk0 + i, NBINS - 1);
-            const float2 pw = pbuf[k];
-            const float rwi = melw[i * 64 + lane], fwi = melw[(8 + i) * 64 + lane];
-            ra = fmaf(rwi, pw.x, ra);
-            fa_ = fmaf(fwi, pw.x, fa_);
-            rb = fmaf(rwi, pw.y, rb);
-            fb_ = fmaf(fwi, pw.y, fb_);
-        }
-        wave_lds_order();
-        cbuf[lane] = make_float4(ra, fa_, rb, fb_);
-        wave_lds_order();
-        float la = 0.f, lb = 0.f;
-        if (lane < p.nfilt) {
-            const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
-            float sa = 0.f, sb = 0.f;
-            for (int i = 0; i < nr; ++i) {
-                const float4 qv = cbuf[r0 + i];
-                sa += qv.x;
-                sb += qv.z;
-            }
-            for (int i = 0; i < nq; ++i) {
-                const float4 qv = cbuf[q0 + i];
-                sa += qv.y;
-                sb += qv.w;
-            }
-            la = logf(sa == 0.f ? PSF_EPS : sa);
-            lb = logf(sb == 0.f ? PSF_EPS : sb);
-        }
-        // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
-        // table-rounding error a -36 log-floor would otherwise amplify.
-        const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
-        const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
-        lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
-        lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
-        wave_lds_order();
-
-        // DCT-II(ortho) x lifter: lane -> (frame f = lane>>5, coefficient i = lane&31)
-        {
-            const int f = lane >> 5, i = lane & 31;
-            if (i < p.numcep && (f == 0 || has_b)) {
-                const float4* L4 = reinterpret_cast<const float4*>(lbuf + 64 * f);
-                const float4* D4 = reinterpret_cast<const float4*>(dctb + i * nfp);
-                float acc = 0.f;
-                for (int j = 0; j < nfp / 4; ++j) {
-                    const float4 d = D4[j], l = L4[j];
-                    acc = fmaf(d.x, l.x, acc);
-                    acc = fmaf(d.y, l.y, acc);
-                    acc = fmaf(d.z, l.z, acc);
-                    acc = fmaf(d.w, l.w, acc);
-                }
-                if (i == 0) {
-                    if (p.append_energy) {
-                        const float e = f ? eb : ea;
-                        acc = logf(e == 0.f ? PSF_EPS : e);
-                    } else {
-                        float dsum = 0.f;
-                        for (int j = 0; j < p.nfilt; ++j) dsum += dctb[j];
-                        acc = fmaf(f ? mb : ma, dsum, acc);
-                    }
-                }
-                out[((size_t)clip * p.num_frames + (fa + f)) * p.numcep + i] = acc;
-            }
-        }
+        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, mk0, gth, lane,
+                  out + ((size_t)clip * p.num_frames + fa) * p.numcep,
+                  out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
         wave_lds_order();
     }
 }
@@ -453,6 +484,118 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming front end (BASELINE config 5: 10 ms hops): every push brings frame_step new samples per stream
+// and completes exactly one new frame per stream.  One wavefront serves two streams (their frames are the two
+// halves of one packed FFT).  hops = pushes seen BEFORE this one; the new frame is frame hops - 2 of the
+// continuous signal and covers samples [step*(hops-2), step*(hops-2) + frame_len).  Samples of the current hop
+// are taken from d_hop, older ones from the per-stream PCM ring (which this kernel also updates).
+__global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, FrontendTables t,
+                                                              const int16_t* __restrict__ hop, int n_streams,
+                                                              int16_t* __restrict__ pcm_ring, int ring_len,
+                                                              float* __restrict__ feat_ring,
+                                                              const int* __restrict__ hops_ptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nfp = (p.nfilt + 3) & ~3;
+    float* dctb = reinterpret_cast<float*>(smem);
+    float* melw = dctb + p.numcep * nfp;
+    cf* tw2 = reinterpret_cast<cf*>(melw + 16 * 64);
+    unsigned char* scr = reinterpret_cast<unsigned char*>(tw2 + 64);
+    const int lane = threadIdx.x;
+    const int sa = 2 * blockIdx.x, sb = sa + 1;
+    const bool has_b = sb < n_streams;
+    const int hops = *hops_ptr;
+    const int step = p.frame_step;
+    const long base = (long)step * hops;            // absolute index of the first sample of this hop
+
+    for (int i = lane; i < p.numcep * nfp; i += 64) {
+        const int r = i / nfp, j = i % nfp;
+        dctb[i] = j < p.nfilt ? t.dct[r * p.nfilt + j] : 0.f;
+    }
+    for (int i = lane; i < 16 * 64; i += 64) melw[i] = i < 8 * 64 ? t.mel_rw[i] : t.mel_fw[i - 8 * 64];
+    fill_tw2(t.twiddle, tw2, lane);
+    cf t1[8];
+    load_twiddles(t.twiddle, lane, t1);
+    const int mk0 = t.mel_k0[lane];
+    const uint32_t gth = t.mel_gather[lane];
+
+    // sample n (absolute) of stream s: current hop -> d_hop, recent past -> ring, before the stream began -> 0
+    auto sample = [&](int s, long n) -> float {
+        if (n < 0) return 0.f;
+        const int16_t v = n >= base ? hop[(size_t)s * step + (int)(n - base)] : pcm_ring[(size_t)s * ring_len + (int)(n % ring_len)];
+        return to_unit(v);
+    };
+    const long f_start = base + step - ((p.frame_len + step - 1) / step) * step;  // = step * (hops - 2) for 400/160
+    const bool frame_ok = f_start >= 0;
+    const long fidx = f_start / step;
+    cf v[8];
+    bool nza = false, nzb = false;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int i = 64 * n1 + lane;
+        float ya = 0.f, yb = 0.f;
+        if (frame_ok && i < p.frame_len) {
+            const long n = f_start + i;
+            const float ca = sample(sa, n);
+            ya = n > 0 ? __fsub_rn(ca, __fmul_rn(p.preemph, sample(sa, n - 1))) : ca;
+            if (has_b) {
+                const float cb = sample(sb, n);
+                yb = n > 0 ? __fsub_rn(cb, __fmul_rn(p.preemph, sample(sb, n - 1))) : cb;
+            }
+        }
+        v[n1].x = ya;
+        v[n1].y = yb;
+        nza |= ya != 0.f;
+        nzb |= yb != 0.f;
+    }
+    nza = __any(nza);
+    nzb = __any(nzb);
+    wave_lds_order();
+    if (frame_ok) {
+        const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
+                                reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
+                                dctb, melw, tw2, nfp};
+        const int row = (int)(fidx % p.num_frames);
+        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, mk0, gth, lane,
+                  feat_ring + ((size_t)sa * p.num_frames + row) * p.numcep,
+                  feat_ring + ((size_t)sb * p.num_frames + row) * p.numcep);
+    }
+    // append the hop to the rings (after every read of older samples above: same wavefront, program order)
+    for (int i = lane; i < step; i += 64) {
+        const int pos = (int)((base + i) % ring_len);
+        pcm_ring[(size_t)sa * ring_len + pos] = hop[(size_t)sa * step + i];
+        if (has_b) pcm_ring[(size_t)sb * ring_len + pos] = hop[(size_t)sb * step + i];
+    }
+}
+
+__global__ void kws_stream_tick_kernel(int* hops) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) hops[0] += 1;
+}
+
+// Augmentation of the reference's training transform (kws/libs/audio_processor.py:151-159, 172-233) for a whole
+// batch: out[b][i] = (silence_b ? 0 : x_b[i - shift_b] / 32768, zero outside the clip) + vol_b * bg[off_b + i],
+// float32 with the same two roundings NumPy makes.
+__global__ void kws_augment_i16_kernel(const int16_t* __restrict__ wav, int B, int n, const int32_t* __restrict__ shift,
+                                       const float* __restrict__ bg, int bg_len, const int32_t* __restrict__ bg_off,
+                                       const float* __restrict__ bg_vol, const uint8_t* __restrict__ silence,
+                                       float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int sh = shift ? shift[b] : 0;
+    const bool sil = silence && silence[b];
+    const float vol = (bg && bg_vol) ? bg_vol[b] : 0.f;
+    const int off = (bg && bg_off) ? bg_off[b] : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = i - sh;
+        float a = (!sil && j >= 0 && j < n) ? to_unit(wav[(size_t)b * n + j]) : 0.f;
+        if (bg) {
+            const int k = off + i;
+            const float g = (k >= 0 && k < bg_len) ? bg[k] : 0.f;
+            a = __fadd_rn(a, __fmul_rn(g, vol));
+        }
+        out[(size_t)b * n + i] = a;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -484,6 +627,34 @@ hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTab
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
                            float* d_out) {
     return launch_mfcc_t(kws_mfcc_f32_kernel, s, p, t, d_wav, B, d_out);
+}
+
+hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, const int* d_hops) {
+    const int nfp = (p.nfilt + 3) & ~3;
+    const size_t lds = sizeof(float) * (size_t)(p.numcep * nfp + 16 * 64 + 2 * 64) + SCR_BYTES;
+    hipLaunchKernelGGL(kws_stream_frame_kernel, dim3((n_streams + 1) / 2), dim3(64), lds, s, p, t, d_hop, n_streams,
+                       d_pcm_ring, ring_len, d_feat_ring, d_hops);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_tick(hipStream_t s, int* d_hops) {
+    hipLaunchKernelGGL(kws_stream_tick_kernel, dim3(1), dim3(64), 0, s, d_hops);
+    return hipGetLastError();
+}
+
+hipError_t launch_augment(hipStream_t s, const int16_t* d_wav, int B, int n, const int32_t* d_shift, const float* d_bg,
+                          int bg_len, const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence,
+                          float* d_out) {
+    int bx = (n + 255) / 256;
+    if (bx > 64) bx = 64;
+    for (int b0 = 0; b0 < B; b0 += 65535) {
+        const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
+        hipLaunchKernelGGL(kws_augment_i16_kernel, dim3(bx, nb), dim3(256), 0, s, d_wav + (size_t)b0 * n, nb, n,
+                           d_shift ? d_shift + b0 : nullptr, d_bg, bg_len, d_bg_off ? d_bg_off + b0 : nullptr,
+                           d_bg_vol ? d_bg_vol + b0 : nullptr, d_silence ? d_silence + b0 : nullptr, d_out + (size_t)b0 * n);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_preemphasis(hipStream_t s, const float* d_in, int n, float coeff, float* d_out) {

@@ -42,6 +42,12 @@ SIGNATURES = {
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
     "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
+    "kws_stream_open": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_stream_close": (C.c_int, [_c_ctx]),
+    "kws_stream_push_i16": (C.c_int, [_c_ctx, _i16p, _f32p, _i32p, C.c_int]),
+    "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
+    "kws_augment_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_void_p, _f32p, C.c_void_p, _f32p]),
     "kws_forward_stamps_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, C.c_void_p, C.c_int]),
     "kws_preemphasis_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_float, _f32p]),
     "kws_framesig_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _f32p]),
@@ -179,6 +185,38 @@ class Context:
         self._check(
             self._lib.kws_infer_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
             ModelError,
+        )
+
+    # -- streaming -------------------------------------------------------------------------------
+    def stream_open(self, n_streams: int):
+        self._check(self._lib.kws_stream_open(self._h, int(n_streams)), AudioProcessingError)
+
+    def stream_close(self):
+        self._check(self._lib.kws_stream_close(self._h))
+
+    def stream_push_i16(self, hop, logits=None, label=None, use_graph=False):
+        self._check(
+            self._lib.kws_stream_push_i16(self._h, _ptr(hop), _ptr(logits) if logits is not None else None,
+                                          _ptr(label) if label is not None else None, 1 if use_graph else 0),
+            ModelError,
+        )
+
+    def stream_state(self):
+        """(device address of the feature ring, pushes so far)."""
+        ring, hops = C.c_void_p(), C.c_int()
+        self._check(self._lib.kws_stream_state(self._h, C.byref(ring), C.byref(hops)))
+        return ring.value, hops.value
+
+    def stream_copy_features(self, out):
+        self._check(self._lib.kws_stream_copy_features(self._h, _ptr(out)))
+
+    # -- augmentation ----------------------------------------------------------------------------
+    def augment_i16(self, wav, out, shift=None, bg=None, bg_off=None, bg_vol=None, silence=None):
+        p = lambda t: _ptr(t) if t is not None else None
+        self._check(
+            self._lib.kws_augment_i16(self._h, _ptr(wav), int(wav.shape[0]), p(shift), p(bg), int(bg.numel()) if bg is not None else 0,
+                                      p(bg_off), p(bg_vol), p(silence), _ptr(out)),
+            AudioProcessingError,
         )
 
     def reserve(self, max_batch: int):

@@ -62,3 +62,58 @@ def inference(test_audio, spotter: Optional[KeywordSpotter] = None):
     idx, word = spotter.infer_files([test_audio])[0]
     print(idx, word)
     return idx, word
+
+
+class StreamingSpotter:
+    """Sliding-window spotting over concurrent live streams (10 ms hops).
+
+    The reference's live path captures a VAD-segmented utterance, writes a wav and classifies it once
+    (``kws/inference/inference_local.py:114-192``).  Here every ``push`` of ``frame_step`` new samples per
+    stream adds one MFCC frame to a 99-frame ring on the GPU and re-classifies the last second of every
+    stream (``kws_stream_push_i16``); with ``use_graph`` the three launches of a push replay as one hipGraph.
+    """
+
+    def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
+                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = True):
+        from kws import _native
+
+        self.config = config or AudioConfig()
+        self.words = list(words)
+        self.model = model if model is not None else DepthwiseSeparableConv(num_classes=len(self.words))
+        self.n_streams = int(n_streams)
+        self.hop = int(round(self.config.frame_step * self.config.sample_rate))
+        self.device = torch.device("cuda", device)
+        self.use_graph = use_graph
+        self._ctx = _native.Context(device, ModelError)
+        self._ctx.load_dscnn(self.model.packed_weights(), self.model.num_classes)
+        self._ctx.stream_open(self.n_streams)
+        self._hop_buf = torch.zeros((self.n_streams, self.hop), dtype=torch.int16, device=self.device)
+        self._logits = torch.zeros((self.n_streams, self.model.num_classes), dtype=torch.float32, device=self.device)
+        self._labels = torch.zeros((self.n_streams,), dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+
+    def push(self, samples) -> Tuple[np.ndarray, np.ndarray]:
+        """``int16[n_streams, hop]`` (host array or device tensor) -> (labels int32[S], logits float32[S,C])."""
+        x = samples if isinstance(samples, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(samples, dtype=np.int16))
+        if tuple(x.shape) != (self.n_streams, self.hop) or x.dtype != torch.int16:
+            raise ModelError(f"push expects int16 [{self.n_streams}, {self.hop}]")
+        self._hop_buf.copy_(x, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()  # the context runs on its own stream
+        self._ctx.stream_push_i16(self._hop_buf, self._logits, self._labels, use_graph=self.use_graph)
+        self._ctx.sync()
+        return self._labels.cpu().numpy(), self._logits.cpu().numpy()
+
+    def features(self) -> np.ndarray:
+        """The current windows, oldest frame first: float32 [S, 99, 10] (zeros where no frame exists yet)."""
+        _, hops = self._ctx.stream_state()
+        t, f = 99, 10
+        tmp = torch.empty((self.n_streams, t, f), dtype=torch.float32, device=self.device)
+        self._ctx.stream_copy_features(tmp)
+        self._ctx.sync()
+        host = tmp.cpu().numpy()
+        head = (hops - 2) % t
+        return np.roll(host, -head, axis=1), hops
+
+    def close(self):
+        self._ctx.stream_close()
+        self._ctx.close()

@@ -203,6 +203,49 @@ class AudioProcessor:
             x = torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float32)).to(dev)[None]
         return self.extract_features_batch(x, _ctx=ctx)[0, 0].double().cpu().numpy()
 
+    def transform_batch(self, pcm, labels):
+        """Batched, on-device version of ``transform`` for clips already decoded to ``int16[B, n]``:
+        silence zeroing, random time shift, background mix (``kws_augment_i16``) and MFCC (``kws_mfcc_f32``).
+        The random draws are made on the host with the same NumPy / random calls as the reference
+        (``:172-233``); returns ``float32[B,1,frames,numcep]`` on the device."""
+        import torch
+
+        c = self.config
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        labels = np.asarray(labels)
+        B, n = pcm.shape
+        if n != c.desired_samples:
+            raise AudioProcessingError(f"transform_batch expects clips of {c.desired_samples} samples")
+        limit = c.time_shift
+        shift = np.array([np.random.randint(-limit, limit) if limit > 0 else 0 for _ in range(B)], dtype=np.int32)
+        silence = (labels == SILENCE_INDEX).astype(np.uint8)
+        dev = torch.device("cuda", self.device)
+        ctx = self._context(n, c.sample_rate, c.num_cepstral_coeffs, c.frame_length, c.frame_step, c.num_mel_filters)
+        bg = bg_off = bg_vol = None
+        if self.background_data and (c.use_background_noise or silence.any()):
+            pool, starts = getattr(self, "_bg_pool", None), getattr(self, "_bg_starts", None)
+            if pool is None:
+                clips = [np.tile(b, int(np.ceil(n / len(b))) + 1) if len(b) <= n else b for b in self.background_data]
+                starts = np.cumsum([0] + [len(b) for b in clips[:-1]])
+                pool = torch.from_numpy(np.concatenate(clips).astype(np.float32)).to(dev)
+                self._bg_pool, self._bg_starts, self._bg_lens = pool, starts, [len(b) for b in clips]
+            off, vol = np.zeros(B, np.int32), np.zeros(B, np.float32)
+            for i in range(B):
+                if not (c.use_background_noise or silence[i]):
+                    continue
+                k = random.randrange(len(self.background_data))
+                off[i] = self._bg_starts[k] + np.random.randint(0, self._bg_lens[k] - n)
+                if silence[i]:
+                    vol[i] = np.random.uniform(0, 1)
+                elif np.random.uniform(0, 1) < c.background_frequency:
+                    vol[i] = np.random.uniform(0, c.background_volume)
+            bg, bg_off, bg_vol = self._bg_pool, torch.from_numpy(off).to(dev), torch.from_numpy(vol).to(dev)
+        out = torch.empty((B, n), dtype=torch.float32, device=dev)
+        ctx.use_torch_stream()
+        ctx.augment_i16(torch.from_numpy(pcm).to(dev), out, shift=torch.from_numpy(shift).to(dev), bg=bg, bg_off=bg_off,
+                        bg_vol=bg_vol, silence=torch.from_numpy(silence).to(dev))
+        return self.extract_features_batch(out, _ctx=ctx)
+
     def extract_features_batch(self, signals, _ctx=None):
         """``int16[B,n]`` (PCM) or ``float32[B,n]`` device tensor -> ``float32[B,1,frames,numcep]`` device tensor:
         the batch the reference builds with ``__getitem__`` + default collate (``kws/libs/data_loader.py:96-105``)."""

@@ -383,3 +383,83 @@ def test_own_stream_and_profiling_counters(native, dev):
         assert np.array_equal(logits.cpu().numpy(), l2)
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------------------------------- augmentation
+def test_augment_matches_numpy_bit_exact(ctx, dev):
+    rng = np.random.default_rng(21)
+    B, n = 9, 16000
+    clips = synth_clips(B, 9, "gauss")
+    shift = rng.integers(-1600, 1600, B).astype(np.int32)
+    shift[0], shift[1] = 0, 1599
+    bg = (rng.standard_normal(50000) * 0.1).astype(np.float32)
+    off = rng.integers(0, 50000 - n, B).astype(np.int32)
+    vol = rng.uniform(0, 1, B).astype(np.float32)
+    vol[2] = 0.0
+    sil = np.zeros(B, np.uint8)
+    sil[3] = 1
+    out = torch.empty((B, n), dtype=torch.float32, device=dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ctx.augment_i16(t(clips), out, shift=t(shift), bg=t(bg), bg_off=t(off), bg_vol=t(vol), silence=t(sil))
+    ctx.sync()
+    want = np.empty((B, n), np.float32)
+    for b in range(B):
+        a = np.zeros(n, np.float32)
+        if not sil[b]:
+            x = o_mfcc.pcm16_to_float(clips[b])
+            s = int(shift[b])
+            if s >= 0:
+                a[s:] = x[: n - s]
+            else:
+                a[: n + s] = x[-s:]
+        want[b] = a + bg[off[b]: off[b] + n] * vol[b]          # float32 array * float32 scalar, as NumPy does
+    assert np.array_equal(out.cpu().numpy(), want)
+    # no background pool, no shift: plain PCM scaling
+    ctx.augment_i16(t(clips), out)
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), o_mfcc.pcm16_to_float(clips))
+
+
+# ------------------------------------------------------------------------------------------- streaming
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_streaming_frames_and_labels(native, dev, use_graph):
+    from kws.inference import StreamingSpotter
+    from kws.libs.models import DepthwiseSeparableConv
+
+    S, hops = 5, 112                     # odd stream count: the last wavefront carries a single stream
+    torch.manual_seed(5)
+    model = DepthwiseSeparableConv(12)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.copy_(torch.randn_like(prm) * 0.1)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(31)
+    pcm = rng.integers(-20000, 20000, size=(S, hops * 160), dtype=np.int16)
+    pcm[1, : 40 * 160] = 0              # a stream that starts with digital silence
+    sp = StreamingSpotter(S, model, use_graph=use_graph)
+    try:
+        checks = {2, 3, 50, 99, 100, 101, hops - 1}
+        for t in range(hops):
+            labels, logits = sp.push(pcm[:, t * 160:(t + 1) * 160])
+            if t not in checks:
+                continue
+            feats, pushed = sp.features()
+            assert pushed == t + 1
+            newest = t - 2                  # newest complete frame of the continuous signal
+            want = np.zeros((S, 99, 10), np.float32)
+            for s in range(S):
+                sig = o_mfcc.pcm16_to_float(pcm[s, : (t + 1) * 160])
+                spec = o_mfcc.FrontendSpec(n_samples=len(sig))
+                allf = o_mfcc.mfcc(sig, spec)    # frames of the continuous signal (the tail frames are zero-padded: unused)
+                for i in range(99):
+                    f = newest - 98 + i
+                    if 0 <= f <= newest:
+                        want[s, i] = allf[f]
+            assert np.abs(feats - want).max() <= TOL, f"hop {t}"
+            ref = o_dscnn.forward(state, torch.from_numpy(want)[:, None])
+            assert np.abs(logits - ref.numpy()).max() <= TOL, f"hop {t}"
+            top2 = torch.topk(ref, 2, dim=1).values
+            clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()
+            assert np.array_equal(labels[clear], o_dscnn.predict(ref).numpy()[clear])
+    finally:
+        sp.close()
