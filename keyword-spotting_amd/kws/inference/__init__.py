@@ -74,7 +74,7 @@ class StreamingSpotter:
     """
 
     def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
-                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = True):
+                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False):
         from kws import _native
 
         self.config = config or AudioConfig()
