@@ -111,12 +111,24 @@ int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, in
  * allocates and must not happen inside stream capture). */
 int kws_reserve(kws_ctx* ctx, int max_batch);
 
+/* Arithmetic of the 1x1 (pointwise) convolutions on the matrix cores -- replaces nothing in the reference
+ * (torch's f32 conv2d, kws/libs/models.py:104-106); both settings keep the logits within 1e-4 of it.
+ *   KWS_PW_SPLIT_BF16 (default): every f32 operand is split exactly into three bf16 pieces (hi + mid + lo == x)
+ *     and the six piece products of combined order <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16;
+ *     each bf16 x bf16 product is exact, the dropped terms are <= 2^-24 relative -- the size of one f32
+ *     rounding -- and the bf16 matrix pipe runs beside the VALU that evaluates the depthwise stencil.
+ *   KWS_PW_F32: v_mfma_f32_32x32x2_f32 (shares the FP32 datapath with the VALU; slower).
+ * Changing it invalidates a captured streaming graph (re-captured on the next push). */
+#define KWS_PW_F32 1
+#define KWS_PW_SPLIT_BF16 4
+int kws_set_pointwise_math(kws_ctx* ctx, int math);
+
 /* Debug/parity aid: run the DS-CNN and also store every stored activation per clip to d_act
  * (float32 [B, KWS_ACT_FLOATS_PER_CLIP]): conv1 out [64][47*3], block1 out interior [64][47*3],
  * block2 out interior [64][49*5], block3 out interior [64][51*7], pooled mean [64].  "Interior" =
  * the pointwise output without the relu(bias) ring its padding=1 adds (models.py:104-106).
- * use_mfma: 1 = the product kernel, 0 = a variant whose pointwise / conv1 GEMMs run on the VALU (an
- * independent check of the matrix-core operand mapping). */
+ * use_mfma: KWS_PW_SPLIT_BF16 (4) / KWS_PW_F32 (1) = the two matrix-core kernels, 0 = a variant whose
+ * pointwise / conv1 GEMMs run on the VALU (an independent check of the matrix-core operand mappings). */
 #define KWS_ACT_FLOATS_PER_CLIP (64 * (141 + 141 + 245 + 357) + 64)
 int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label,
                           float* d_act, int use_mfma);
@@ -152,9 +164,9 @@ int kws_augment_i16(kws_ctx* ctx, const int16_t* d_wav, int B, const int32_t* d_
 /* Diagnostics: the same forward with per-clip shader-clock stamps (s_memtime of thread 0) at the phase
  * boundaries of the DS-CNN kernel, uint64 [B, KWS_DSCNN_STAMPS]: 0 start, 1 features staged, 2/3 conv1
  * done / barrier, 4/5 .. 10/11 blocks 1..4 done / barrier, 12 end; [14], [15] = 100 MHz real-time
- * counter at start / end.  mode: 1 = the product kernel, 0 = VALU cross-check variant, 2 / 3 = timing
- * ablations (matrix core only / stencil only: wrong results by construction).  Never used on the
- * product path. */
+ * counter at start / end.  mode: KWS_PW_SPLIT_BF16 (4) / KWS_PW_F32 (1) = the matrix-core kernels, 0 = VALU
+ * cross-check variant, 2 / 3 = timing ablations of the f32 kernel (matrix core only / stencil only), 6 = of
+ * the split kernel (no stencil): wrong results by construction.  Never used on the product path. */
 #define KWS_DSCNN_STAMPS 16
 int kws_forward_stamps_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode);
 

@@ -126,6 +126,7 @@ struct kws_ctx {
     float* d_model = nullptr;
     DscnnWeights mw{};
     bool model_ready = false;
+    int pw_math = KWS_PW_SPLIT_BF16;  // kernel variant of the product entry points
 
     // workspace (MFCC features between the two kernels of kws_infer_i16)
     float* d_feat_ws = nullptr;
@@ -358,7 +359,8 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     }
     // repack: c1_w [100][64] | c1_b [64] | dw [4][64][12] | pw_w [4][cin][cout] | pw_b [4][64] | fc_w | fc_b
     const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
-                 o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64, total = o_fcb + num_classes;
+                 o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64,
+                 o_split = (o_fcb + num_classes + 3) & ~(size_t)3, total = o_split + 4 * 2 * 4 * 3 * 64 * 4;
     std::vector<float> h(total, 0.f);
     const float* src = blob;
     for (int co = 0; co < 64; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
@@ -375,6 +377,26 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
         for (int co = 0; co < 64; ++co)  // pointwise.weight [cout][cin][1][1] -> [cin][cout]
             for (int ci = 0; ci < 64; ++ci) h[o_pww + (size_t)b * 4096 + (size_t)ci * 64 + co] = pw_w[co * 64 + ci];
         memcpy(&h[o_pwb + (size_t)b * 64], pw_b, 64 * sizeof(float));
+        // the same weights as bf16x3 MFMA A operands (32x32x16): lane l of (ct, m) holds cin = 16m + 8(l>>5) + j,
+        // j = 0..7, of cout = 32ct + (l&31); piece 0/1/2 = top 16 bits of the value / first / second remainder
+        uint32_t* sp = reinterpret_cast<uint32_t*>(&h[o_split]) + (size_t)b * (2 * 4 * 3 * 64 * 4);
+        for (int ct = 0; ct < 2; ++ct)
+            for (int m = 0; m < 4; ++m)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * ct + (l & 31), ci = 16 * m + 8 * (l >> 5) + j;
+                        float r = pw_w[co * 64 + ci];
+                        for (int p = 0; p < 3; ++p) {
+                            uint32_t u;
+                            memcpy(&u, &r, 4);
+                            u &= 0xffff0000u;
+                            float t;
+                            memcpy(&t, &u, 4);
+                            r -= t;
+                            uint32_t& dst = sp[(((size_t)(ct * 4 + m) * 3 + p) * 64 + l) * 4 + (j >> 1)];
+                            dst |= (u >> 16) << (16 * (j & 1));
+                        }
+                    }
         src += 576 + 64 + 4096 + 64;
     }
     memcpy(&h[o_fcw], src, (size_t)num_classes * 64 * sizeof(float));
@@ -398,6 +420,7 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     c->mw.dw_w = d + o_dw;
     c->mw.pw_w = d + o_pww;
     c->mw.pw_b = d + o_pwb;
+    c->mw.pw_split = reinterpret_cast<const uint32_t*>(d + o_split);
     c->mw.fc_w = d + o_fcw;
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
@@ -466,16 +489,33 @@ static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits,
 }
 
 int kws_forward_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label) {
-    return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, 1, "kws_forward_f32");
+    return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, c ? c->pw_math : 0, "kws_forward_f32");
+}
+
+int kws_set_pointwise_math(kws_ctx* c, int math) {
+    if (!c) return KWS_EINVAL;
+    if (math != KWS_PW_F32 && math != KWS_PW_SPLIT_BF16)
+        return fail(c, KWS_EINVAL, "kws_set_pointwise_math: math must be KWS_PW_F32 or KWS_PW_SPLIT_BF16");
+    if (math != c->pw_math && c->stream_graph) {  // the captured graph holds the other kernel
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipGraphExecDestroy(c->stream_graph);
+        c->stream_graph = nullptr;
+    }
+    c->pw_math = math;
+    return KWS_OK;
 }
 
 int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                           int use_mfma) {
+    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16)
+        return fail(c, KWS_EINVAL, "kws_forward_debug_f32: use_mfma must be 0, KWS_PW_F32 or KWS_PW_SPLIT_BF16");
     return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma, "kws_forward_debug_f32");
 }
 
 int kws_forward_stamps_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode) {
     if (!d_stamps) return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: d_stamps is NULL");
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 6)
+        return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: unknown kernel variant");
     return forward_impl(c, d_feat, B, d_logits, nullptr, nullptr, mode, "kws_forward_stamps_f32",
                         reinterpret_cast<unsigned long long*>(d_stamps));
 }
@@ -490,7 +530,7 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     if (rc) return rc;
     rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
     if (rc) return rc;
-    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, 1, "kws_infer_i16");
+    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, c->pw_math, "kws_infer_i16");
 }
 
 // ---- streaming ------------------------------------------------------------------------------------
@@ -545,7 +585,7 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
     e = launch_stream_tick(c->stream, c->d_hops);
     if (e != hipSuccess) return e;
     if (d_logits)
-        e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, 1, nullptr, c->d_hops);
+        e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, c->pw_math, nullptr, c->d_hops);
     return e;
 }
 

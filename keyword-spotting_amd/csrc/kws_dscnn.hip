@@ -39,6 +39,8 @@ namespace kws {
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
 #ifndef KWS_DSCNN_WAVES
 #define KWS_DSCNN_WAVES 8
@@ -120,13 +122,64 @@ __device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, c
     if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b;
 }
 
-// Pointwise weights of block n as MFMA A operands: wa[ct][s] = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)].
-__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, float (&wa)[2][32]) {
-    const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
+// Pointwise weights of the running block as MFMA A operands, held in registers for the whole block.
+//   f32 path   (32x32x2 f32):   wa[ct][s]   = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)]
+//   split path (32x32x16 bf16): f[ct][m][p] = piece p (0 hi, 1 mid, 2 lo) of W[cout = ct*32 + (l&31)][cin = 16m + 8(l>>5) + j],
+//                               j = 0..7 -- eight bf16 per lane, pre-split on the host (exactly: hi + mid + lo == W)
+template <bool SPLIT>
+struct PwRegs {
+    float wa[2][32];
+};
+template <>
+struct PwRegs<true> {
+    uintx4 f[2][4][3];
+};
+template <int MODE>
+using PwOperands = PwRegs<(MODE >= 4)>;
+template <int MODE>
+__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwOperands<MODE>& o) {
+    if constexpr (MODE >= 4) {
+        const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) wa[ct][s] = pw[2 * s * CH + ct * 32];
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) o.f[ct][m][p] = src[((ct * 4 + m) * 3 + p) * 64];
+    } else {
+        const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[2 * s * CH + ct * 32];
+    }
+}
+
+// Exact three-way split of eight f32 values into bf16 pieces (y == hi + mid + lo, each piece the top 16 bits of
+// the running remainder), packed as MFMA B operands.  bf16 x bf16 products are exact in the matrix core's f32
+// accumulate, so the six products with combined order <= 2 reproduce the f32 product to ~2^-24 relative.
+__device__ __forceinline__ uint32_t pack_top16(float even, float odd) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, odd), __builtin_bit_cast(uint32_t, even), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float v) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
+}
+__device__ __forceinline__ void split3(const float (&y)[8], uintx4& hi, uintx4& mid, uintx4& lo) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r1[j] = y[j] - top16(y[j]);
+        r2[j] = r1[j] - top16(r1[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = pack_top16(y[2 * i], y[2 * i + 1]);
+        mid[i] = pack_top16(r1[2 * i], r1[2 * i + 1]);
+        lo[i] = pack_top16(r2[2 * i], r2[2 * i + 1]);
+    }
+}
+__device__ __forceinline__ floatx16 mfma_bf16(const uintx4& a, const uintx4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,12 +231,16 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 // ------------------------------------------------------------------------------------------------
 // One depthwise-separable block.  wa: pointwise weights of THIS block on entry; on exit (N < 4) the
 // loads of the next block's weights have been issued into it, so they fly across the barrier.
-// MODE: 0 = pointwise GEMM on the VALU (cross-check of the MFMA operand mapping), 1 = product path,
-// 2 / 3 = timing ablations (matrix core only / stencil only; wrong results by construction).
+// MODE: 0 = pointwise GEMM on the VALU (cross-check of the MFMA operand mappings), 1 = f32 MFMA,
+// 4 = split-bf16 MFMA (product path), 2 / 3 = timing ablations of mode 1 (matrix core only / stencil only;
+// wrong results by construction).
 template <int N, int MODE>
-__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, float (&wa)[2][32]) {
+__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo) {
     using G = Blk<N>;
     constexpr bool MFMA = MODE != 0;
+    constexpr bool SPLIT = MODE >= 4;  // input channel of step s: 16(s>>3) + 8*half + (s&7) instead of 2s + half
+    // timing ablation of the split path (wrong results by construction): 6 = split + matrix core without the stencil
+    constexpr bool NO_STENCIL = MODE == 6;
     const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
     float* zout = lds + G::OFF_OUT;
     const float* dwtab = lds + OFF_DWTAB + G::BUF * 768;
@@ -206,7 +263,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 
     // accumulator rows 4q..4q+3 of tile ct are output channels ct*32 + 8q + 4*half + (0..3): one float4
     const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
-    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 3;
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * (SPLIT ? 24 : 3);
     float psum[2][16];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -231,7 +288,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
             const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
             const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
-            tlo[dh + 1] = G::OFF_IN + a + half * G::SIN;
+            tlo[dh + 1] = G::OFF_IN + a + half * (SPLIT ? 8 : 1) * G::SIN;
             thi[dh + 1] = tlo[dh + 1] + 32 * G::SIN;
             asm volatile("" : "+v"(tlo[dh + 1]));
             asm volatile("" : "+v"(thi[dh + 1]));
@@ -241,17 +298,19 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
             float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
         };
+        auto cs_of = [](int s) { return SPLIT ? 16 * (s >> 3) + (s & 7) : 2 * s; };  // channel of step s minus the half's offset
         auto dw_load = [&](int s, Taps& tp) {
-            tp.q0 = dwt4[s * 6 + 0];
-            tp.q1 = dwt4[s * 6 + 1];
-            tp.q2 = dwt4[s * 6 + 2];
-            const int* ta = s < 16 ? tlo : thi;
-            const int o = 2 * (s & 15) * G::SIN;
+            const int cs = cs_of(s);
+            tp.q0 = dwt4[cs * 3 + 0];
+            tp.q1 = dwt4[cs * 3 + 1];
+            tp.q2 = dwt4[cs * 3 + 2];
+            const int* ta = cs < 32 ? tlo : thi;
+            const int o = (cs & 31) * G::SIN;
             tp.up = lds[ta[0] + o];
             tp.mid = lds[ta[1] + o];
             tp.dn = lds[ta[2] + o];
         };
-        // depthwise 3x3 (+bias) of channel 2s + half at this lane's column -> one MFMA B operand
+        // depthwise 3x3 (+bias) of this step's channel at this lane's column -> one MFMA B operand element
         auto dw_eval = [&](const Taps& tp) -> float {
             float c = tp.q2.y;                                     // bias
             c = fmaf(tp.q0.y, tp.up, c);                           // (dh,dx) = (-1, 0)
@@ -282,34 +341,80 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             dw_load(0, ta0);
             dw_load(1, ta1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPLIT) {
+                // eight depthwise outputs fill one k-block of 16 input channels (8 per half-wave); they are split
+                // into three bf16 pieces and multiplied with the pre-split weights: 6 products x 2 channel tiles.
+                // The bf16 matrix pipe runs beside the VALU, so the stencil of the next k-block overlaps them.
+                // The 12 MFMAs of k-block m are issued one per half step while the VALU evaluates the stencil of
+                // k-block m+1 (sched_barrier pins that interleave; left alone, the compiler issues them back to back
+                // and the wavefront sits behind the busy matrix pipe).  Smallest products first.
+                float y[8];
+                uintx4 bh, bm, bl;
+                auto product = [&](int ct, int m, int q) {  // q-th of the six piece products of k-block m, channel tile ct
+                    const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+                    const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
+                    if (ct == 0)
+                        acc0 = mfma_bf16(pwo.f[0][m][pa], b, acc0);
+                    else
+                        acc1 = mfma_bf16(pwo.f[1][m][pa], b, acc1);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
 #pragma unroll
-            for (int s = 0; s < 32; s += 2) {
-                if constexpr (MODE == 1) {
-                    const float y0 = dw_eval(ta0);
-                    if (s + 2 < 32) dw_load(s + 2, ta0);
+                for (int s = 0; s < 32; ++s) {
+                    const int m = s >> 3, j = s & 7;
+                    Taps& tp = (s & 1) ? ta1 : ta0;
+                    const bool feed = m > 0 && j < 6;
+                    if (feed) product(0, m - 1, j);
+                    y[j] = NO_STENCIL ? tp.mid : dw_eval(tp);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
-                    const float y1 = dw_eval(ta1);
-                    if (s + 3 < 32) dw_load(s + 3, ta1);
+                    if (feed) product(1, m - 1, j);
+                    if constexpr (NO_STENCIL) {
+                        if (s + 2 < 32) tp.mid = lds[(cs_of(s + 2) < 32 ? tlo : thi)[1] + (cs_of(s + 2) & 31) * G::SIN];
+                    } else {
+                        if (s + 2 < 32) dw_load(s + 2, tp);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
-                } else if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
-                    const float y0 = ta0.mid, y1 = ta1.mid;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
-                } else {  // MODE 3, timing ablation: stencil only (results are wrong)
-                    const float y0 = dw_eval(ta0);
-                    if (s + 2 < 32) dw_load(s + 2, ta0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc0[0] += y0 * wa[0][s];
-                    const float y1 = dw_eval(ta1);
-                    if (s + 3 < 32) dw_load(s + 3, ta1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc1[0] += y1 * wa[1][s + 1];
+                    if (j == 7) {
+                        split3(y, bh, bm, bl);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    product(0, 3, q);
+                    product(1, 3, q);
+                }
+            } else {
+                auto& wa = pwo.wa;
+#pragma unroll
+                for (int s = 0; s < 32; s += 2) {
+                    if constexpr (MODE == 1) {
+                        const float y0 = dw_eval(ta0);
+                        if (s + 2 < 32) dw_load(s + 2, ta0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
+                        const float y1 = dw_eval(ta1);
+                        if (s + 3 < 32) dw_load(s + 3, ta1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
+                    } else if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
+                        const float y0 = ta0.mid, y1 = ta1.mid;
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
+                    } else {  // MODE 3, timing ablation: stencil only (results are wrong)
+                        const float y0 = dw_eval(ta0);
+                        if (s + 2 < 32) dw_load(s + 2, ta0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc0[0] += y0 * wa[0][s];
+                        const float y1 = dw_eval(ta1);
+                        if (s + 3 < 32) dw_load(s + 3, ta1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc1[0] += y1 * wa[1][s + 1];
+                    }
                 }
             }
             auto epilogue = [&]() {
@@ -333,7 +438,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             // loads fly under the epilogue, the barrier and the next prologue
             if (N < 4 && t + NW >= G::TILES) {
                 __builtin_amdgcn_sched_barrier(0);  // not before the last MFMA has read the old operands
-                if constexpr (N < 4) load_pointwise(w, N + 1, lane, wa);
+                if constexpr (N < 4) load_pointwise<MODE>(w, N + 1, lane, pwo);
                 __builtin_amdgcn_sched_barrier(0);
                 epilogue();
                 break;
@@ -372,7 +477,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
-            if (wv >= G::TILES) load_pointwise(w, N + 1, lane, wa);  // waves without a unit in this block
+            if (wv >= G::TILES) load_pointwise<MODE>(w, N + 1, lane, pwo);  // waves without a unit in this block
         } else {
             // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips)
 #pragma unroll
@@ -387,6 +492,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     }
     (void)bias4;
 }
+
 
 template <int MODE>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
@@ -415,12 +521,12 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     // ---- phase 0: weight loads in flight, MFCC map -> zero-padded [103][14] in LDS ------------------
     float a1[50];        // conv1 weights of this wave's output-channel tile (MFMA A operands)
-    float wa[2][32];     // pointwise weights of the running block
+    PwOperands<MODE> wa;  // pointwise weights of the running block
     if constexpr (MFMA) {
         const int half = lane >> 5, col = lane & 31, ct = wv & 1;
 #pragma unroll
         for (int s = 0; s < 50; ++s) a1[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
-        load_pointwise(w, 1, lane, wa);
+        load_pointwise<MODE>(w, 1, lane, wa);
     }
     float* featp = lds + OFF_FEAT;
     const float* f = feat + (size_t)clip * (IN_T * IN_F);
@@ -545,7 +651,8 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 hipError_t dscnn_init_device() {
     const int lds = LDS_FLOATS * (int)sizeof(float);
     const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -563,6 +670,8 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
         case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 4: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<4>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
     }
     return hipGetLastError();

@@ -97,6 +97,7 @@ struct DscnnWeights {
     const float* dw_w;     // [4][64][12] depthwise 3x3 taps [0..8], bias at [9], 2 pad
     const float* pw_w;     // [4][64][64] pointwise transposed: [cin][cout]
     const float* pw_b;     // [4][64]
+    const uint32_t* pw_split;  // [4][ct 2][m 4][piece 3][lane 64][4]  pointwise weights as bf16 hi/mid/lo MFMA A operands
     const float* fc_w;     // [C][64]
     const float* fc_b;     // [C]
     int num_classes;

@@ -21,6 +21,8 @@ LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 KWS_K_MFCC, KWS_K_DSCNN = 0, 1
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64
+PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
+PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16 (default): exact three-way bf16 split, six bf16 MFMAs per f32 product
 
 _c_ctx = C.c_void_p
 _i16p, _f32p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
@@ -41,6 +43,7 @@ SIGNATURES = {
     "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_set_pointwise_math": (C.c_int, [_c_ctx, C.c_int]),
     "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
     "kws_stream_open": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_close": (C.c_int, [_c_ctx]),
@@ -170,15 +173,18 @@ class Context:
             ModelError,
         )
 
-    def forward_debug_f32(self, feat, logits, label, act, use_mfma=True):
+    def set_pointwise_math(self, math):
+        self._check(self._lib.kws_set_pointwise_math(self._h, int(math)), ModelError)
+
+    def forward_debug_f32(self, feat, logits, label, act, use_mfma=PW_SPLIT_BF16):
         self._check(
             self._lib.kws_forward_debug_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits),
                                             _ptr(label) if label is not None else None,
-                                            _ptr(act) if act is not None else None, 1 if use_mfma else 0),
+                                            _ptr(act) if act is not None else None, int(use_mfma)),
             ModelError,
         )
 
-    def forward_stamps_f32(self, feat, logits, stamps, mode=1):
+    def forward_stamps_f32(self, feat, logits, stamps, mode=PW_SPLIT_BF16):
         self._check(self._lib.kws_forward_stamps_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits), _ptr(stamps), int(mode)), ModelError)
 
     def infer_i16(self, wav, logits, label=None):

@@ -193,7 +193,7 @@ def split_act(act):
 
 
 @pytest.mark.parametrize("tag", ["n01", "default"])
-@pytest.mark.parametrize("use_mfma", [False, True])
+@pytest.mark.parametrize("use_mfma", [0, 1, 4])  # VALU cross-check, f32 MFMA, split-bf16 MFMA
 def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, tag, use_mfma):
     g = dscnn_golden
     blob = g[f"{tag}.blob"]
@@ -236,6 +236,31 @@ def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
     ctx.sync()
     assert torch.equal(a, b)
     assert np.array_equal(la.cpu().numpy(), g["n01.label"])
+
+
+def test_pointwise_math_settings_agree(native, ctx, dev, dscnn_golden):
+    """KWS_PW_SPLIT_BF16 (default) and KWS_PW_F32 are two arithmetic routes to the same f32 result: both within
+    TOL of the reference logits, within 1e-5 of each other, identical labels; unknown settings are refused."""
+    from kws.common.errors import ModelError
+
+    g = dscnn_golden
+    ctx.load_dscnn(g["n01.blob"], 12)
+    x = torch.from_numpy(g["x"]).to(dev)
+    out = {}
+    for math in (native.PW_SPLIT_BF16, native.PW_F32):
+        ctx.set_pointwise_math(math)
+        logits = torch.empty((x.shape[0], 12), dtype=torch.float32, device=dev)
+        labels = torch.empty((x.shape[0],), dtype=torch.int32, device=dev)
+        ctx.forward_f32(x, logits, labels)
+        ctx.sync()
+        out[math] = (logits.cpu().numpy(), labels.cpu().numpy())
+        assert np.abs(out[math][0] - g["n01.logits"]).max() <= TOL
+        assert np.array_equal(out[math][1], g["n01.label"])
+    scale = max(1.0, float(np.abs(g["n01.logits"]).max()))
+    assert np.abs(out[native.PW_SPLIT_BF16][0] - out[native.PW_F32][0]).max() <= 1e-5 * scale
+    with pytest.raises(ModelError):
+        ctx.set_pointwise_math(2)
+    ctx.set_pointwise_math(native.PW_SPLIT_BF16)
 
 
 # ------------------------------------------------------------------------------------------- fused wav -> label

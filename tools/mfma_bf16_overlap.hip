@@ -1,0 +1,70 @@
+// Micro-benchmark (diagnostics): bf16 MFMA (32x32x16) issue rate, and how much VALU a co-resident wave still gets.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE>  // 0: MFMA waves only, 1: VALU waves only, 2: both
+__global__ void k(float* out, unsigned long long* cyc, int iters) {
+    const int wave = threadIdx.x >> 6;
+    const bool mfma_wave = wave < 4;
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    bf16x8 av, bv;
+    for (int i = 0; i < 8; ++i) { av[i] = (__bf16)(a + i); bv[i] = (__bf16)(b - i); }
+    floatx16 acc0 = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, acc1 = acc0;
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = a + i;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (mfma_wave) {
+        if (MODE != 1)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc1, 0, 0, 0);
+                }
+            }
+    } else {
+        if (MODE != 0)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 64; ++u) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], b, a);
+                }
+            }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    for (int i = 0; i < 8; ++i) s += f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name) {
+    const int grid = 256, iters = 64;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, sizeof(float) * grid * 512);
+    hipMalloc(&cyc, sizeof(unsigned long long) * grid * 8);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(512), 0, 0, out, cyc, iters);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(grid * 8);
+    hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    double m = 0, v = 0;
+    for (int g = 0; g < grid; ++g) for (int w = 0; w < 8; ++w) (w < 4 ? m : v) += h[g * 8 + w];
+    m /= grid * 4; v /= grid * 4;
+    printf("%-28s MFMA waves: %8.0f cycles (%.1f per MFMA)   VALU waves: %8.0f cycles (%.2f per v_fma)\n", name, m,
+           m / (iters * 32.0), v, v / (iters * 64.0 * 8));
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    run<0>("bf16 32x32x16 MFMA alone");
+    run<1>("VALU waves alone");
+    run<2>("bf16 MFMA + VALU, same SIMDs");
+    return 0;
+}
