@@ -49,6 +49,7 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
     out.rw.assign(MEL_CHUNK * 64, 0.f);
     out.fw.assign(MEL_CHUNK * 64, 0.f);
     out.gather.assign(64, 0u);
+    out.slot.assign(nfft / 2, 0);
     std::vector<int> seg_first(nfilt + 2, 0), seg_count(nfilt + 2, 0);
     int nchunks = 0;
     // segment s = bins [edge_s, edge_s+1): rising side of filter s (s < nfilt), falling side of filter s-1 (s >= 1)
@@ -61,6 +62,7 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
                 return false;
             }
             out.k0[nchunks] = k0;
+            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) out.slot[k0 + i] = MEL_CHUNK * nchunks + i;
             for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) {
                 const double k = k0 + i, width = (double)(hi - lo);
                 if (s < nfilt) out.rw[i * 64 + nchunks] = (float)((k - lo) / width);
@@ -282,6 +284,8 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     MelHost mel;
     std::string err;
     if (!build_mel_host(nfilt, nfft, sample_rate, mel, err)) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: " + err);
+    if (mel.edges.front() != 0 || mel.edges.back() != nfft / 2)
+        return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: the mel filterbank must span bins 0 .. nfft/2");
     std::vector<float> dct;
     build_dct_lifter_host(nfilt, numcep, ceplifter, dct);
     std::vector<float2> tw;
@@ -291,7 +295,8 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
                  o_fw = al(o_rw + sizeof(float) * MEL_CHUNK * 64), o_g = al(o_fw + sizeof(float) * MEL_CHUNK * 64),
-                 o_dct = al(o_g + sizeof(uint32_t) * 64), total = al(o_dct + sizeof(float) * dct.size());
+                 o_dct = al(o_g + sizeof(uint32_t) * 64), o_slot = al(o_dct + sizeof(float) * dct.size()),
+                 total = al(o_slot + sizeof(int) * (NFFT / 2));
     std::vector<unsigned char> host(total, 0);
     memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
     memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
@@ -299,6 +304,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     memcpy(&host[o_fw], mel.fw.data(), sizeof(float) * MEL_CHUNK * 64);
     memcpy(&host[o_g], mel.gather.data(), sizeof(uint32_t) * 64);
     memcpy(&host[o_dct], dct.data(), sizeof(float) * dct.size());
+    memcpy(&host[o_slot], mel.slot.data(), sizeof(int) * (NFFT / 2));
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
@@ -319,6 +325,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->ft.mel_fw = reinterpret_cast<const float*>(b + o_fw);
     c->ft.mel_gather = reinterpret_cast<const uint32_t*>(b + o_g);
     c->ft.dct = reinterpret_cast<const float*>(b + o_dct);
+    c->ft.mel_slot = reinterpret_cast<const int*>(b + o_slot);
 
     FrontendParams& p = c->fp;
     p.n_samples = n_samples;
@@ -360,11 +367,34 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     // repack: c1_w [100][64] | c1_b [64] | dw [4][64][12] | pw_w [4][cin][cout] | pw_b [4][64] | fc_w | fc_b
     const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
                  o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64,
-                 o_split = (o_fcb + num_classes + 3) & ~(size_t)3, total = o_split + 4 * 2 * 4 * 3 * 64 * 4;
+                 o_split = (o_fcb + num_classes + 3) & ~(size_t)3, o_c1s = o_split + 4 * 2 * 4 * 3 * 64 * 4,
+                 total = o_c1s + 2 * 7 * 3 * 64 * 4;
     std::vector<float> h(total, 0.f);
     const float* src = blob;
     for (int co = 0; co < 64; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
         for (int k = 0; k < 100; ++k) h[o_c1w + (size_t)k * 64 + co] = src[co * 100 + k];
+    {
+        // conv1 as bf16x3 MFMA A operands (32x32x16).  The 100 taps are split between the half-waves: lanes
+        // 32..63 take kernel rows 5..9, so both halves walk the same 50 (+6 zero) offsets f = 10*(kh%5) + kw and
+        // their LDS addresses differ by a constant.  Lane l of (ct, kb): cout = 32ct + (l&31), f = 8kb + j.
+        uint32_t* sp = reinterpret_cast<uint32_t*>(&h[o_c1s]);
+        for (int ct = 0; ct < 2; ++ct)
+            for (int kb = 0; kb < 7; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * ct + (l & 31), f = 8 * kb + j;
+                        float r = f < 50 ? src[co * 100 + (f / 10 + 5 * (l >> 5)) * 10 + f % 10] : 0.f;
+                        for (int p = 0; p < 3; ++p) {
+                            uint32_t u;
+                            memcpy(&u, &r, 4);
+                            u &= 0xffff0000u;
+                            float t;
+                            memcpy(&t, &u, 4);
+                            r -= t;
+                            sp[(((size_t)(ct * 7 + kb) * 3 + p) * 64 + l) * 4 + (j >> 1)] |= (u >> 16) << (16 * (j & 1));
+                        }
+                    }
+    }
     src += 6400;
     memcpy(&h[o_c1b], src, 64 * sizeof(float));
     src += 64;
@@ -421,6 +451,7 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     c->mw.pw_w = d + o_pww;
     c->mw.pw_b = d + o_pwb;
     c->mw.pw_split = reinterpret_cast<const uint32_t*>(d + o_split);
+    c->mw.c1_split = reinterpret_cast<const uint32_t*>(d + o_c1s);
     c->mw.fc_w = d + o_fcw;
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
@@ -507,14 +538,14 @@ int kws_set_pointwise_math(kws_ctx* c, int math) {
 
 int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                           int use_mfma) {
-    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16)
+    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16 && use_mfma != 5)
         return fail(c, KWS_EINVAL, "kws_forward_debug_f32: use_mfma must be 0, KWS_PW_F32 or KWS_PW_SPLIT_BF16");
     return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma, "kws_forward_debug_f32");
 }
 
 int kws_forward_stamps_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode) {
     if (!d_stamps) return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: d_stamps is NULL");
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 6)
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6)
         return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: unknown kernel variant");
     return forward_impl(c, d_feat, B, d_logits, nullptr, nullptr, mode, "kws_forward_stamps_f32",
                         reinterpret_cast<unsigned long long*>(d_stamps));

@@ -76,7 +76,42 @@ struct Blk {
     static constexpr int BUF = (N - 1) & 1;                       // which depthwise / bias buffer it reads
 };
 
-__device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
+// one v_max_f32 (the C++ forms compile to a canonicalising v_max plus the real one)
+__device__ __forceinline__ float relu(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// Depthwise 3x3 (+bias) at this lane's column from its three own-column inputs: nine multiply-adds and two
+// fused DPP multiply-adds that pull the neighbouring lanes' column sums across the wavefront (0 shifted in at the
+// ends).  Written as one asm block so that (a) the shift and the multiply-add are one instruction each
+// (v_fmac_f32_dpp; the compiler emits v_mov_b32_dpp + v_fmac), and (b) each DPP source is written three
+// instructions before it is read -- the VALU-write -> DPP-read hazard needs two wait states and the hazard
+// recognizer does not look inside inline asm.  w0..w8 row-major taps, b bias.  TO_MFMA: the result is fed straight
+// to a matrix-core instruction (f32 path), which needs two more wait states after the last VALU write.
+template <bool TO_MFMA = false>
+__device__ __forceinline__ float stencil3x3(float w0, float w1, float w2, float w3, float w4, float w5, float w6,
+                                            float w7, float w8, float b, float up, float mid, float dn, float mask_l,
+                                            float mask_r) {
+    float c, to_right, to_left;
+    asm("v_mul_f32 %1, %3, %13\n\t"          // to_right = w0*up   (what lane+1 needs: its (.., -1) taps)
+        "v_mul_f32 %2, %5, %13\n\t"          // to_left  = w2*up   (what lane-1 needs: its (.., +1) taps)
+        "v_fma_f32 %0, %4, %13, %12\n\t"     // c = w1*up + b
+        "v_fmac_f32 %1, %6, %14\n\t"         // to_right += w3*mid
+        "v_fmac_f32 %2, %8, %14\n\t"         // to_left  += w5*mid
+        "v_fmac_f32 %0, %7, %14\n\t"         // c += w4*mid
+        "v_fmac_f32 %1, %9, %15\n\t"         // to_right += w6*dn
+        "v_fmac_f32 %2, %11, %15\n\t"        // to_left  += w8*dn
+        "v_fmac_f32 %0, %10, %15\n\t"        // c += w7*dn
+        "v_fmac_f32_dpp %0, %1, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // c += to_right[lane-1]*mask_l
+        "v_fmac_f32_dpp %0, %2, %17 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"        // c += to_left[lane+1]*mask_r
+        : "=&v"(c), "=&v"(to_right), "=&v"(to_left)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7), "v"(w8), "v"(b), "v"(up), "v"(mid),
+          "v"(dn), "v"(mask_l), "v"(mask_r));
+    if constexpr (TO_MFMA) asm volatile("s_nop 1" : "+v"(c));
+    return c;
+}
 __device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // lane i <- lane i-1 / lane i+1 across the whole wavefront (0 shifted in at the ends)
@@ -228,6 +263,77 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
     }
 }
 
+// conv1 on the bf16 matrix pipe (split path).  K order: the half-wave h takes kernel rows 5h..5h+4, so both
+// halves walk the same 56 offsets f = 8kb + j -> (kh%5 = f/10, kw = f%10) (f >= 50: zero weights) and lane
+// (col, h) of k-block kb supplies im2col values feat[2oh + 5h + f/10][2ow + f%10], j = 0..7, split into three bf16
+// pieces like the pointwise operands.  c1f: this wave's channel tile, [kb][piece], loaded at kernel start.
+__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3]) {
+    const float* featp = lds + OFF_FEAT;
+    float* z0 = lds + OFF_Z0;
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int ct = wv & 1;  // units u = wv, wv + NW share the output-channel tile (NW is even)
+    for (int u = wv; u < 10; u += NW) {
+        const int pos = (u >> 1) * 32 + col;
+        const int posc = pos < P0 ? pos : P0 - 1;
+        const int oh = posc / C1_W, ow = posc % C1_W;
+        const float* base = featp + (2 * oh + 5 * half) * FEAT_W + 2 * ow;
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;  // two chains keep the matrix pipe fed
+        float y[2][8];
+        auto gather = [&](int kb, float (&dst)[8]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = base[((8 * kb + j) / 10) * FEAT_W + (8 * kb + j) % 10];
+        };
+        uintx4 bf[2][3];  // [buffer][hi, mid, lo] B operands: k-block kb multiplies while kb+1 is being split
+        gather(0, y[0]);
+        gather(1, y[1]);
+        split3(y[0], bf[0][0], bf[0][1], bf[0][2]);
+        gather(2, y[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb) {
+            const int cur = kb & 1, nxt = cur ^ 1;
+            // the six products of this k-block, smallest first, one per quarter of the next k-block's split
+            auto product = [&](int q) {
+                const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+                const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
+                if (q & 1)
+                    acc2 = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc2);
+                else
+                    acc = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                product(i);
+                if (kb + 1 < 7) {
+                    const float a0 = y[nxt][2 * i], a1 = y[nxt][2 * i + 1];
+                    const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
+                    bf[nxt][0][i] = pack_top16(a0, a1);
+                    bf[nxt][1][i] = pack_top16(r0, r1);
+                    bf[nxt][2][i] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            product(4);
+            if (kb + 3 < 7) gather(kb + 3, y[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            product(5);
+        }
+        acc += acc2;
+        if (pos < P0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * 32 + row_of(r, half);
+                z0[co * (P0 + 2) + pos] = relu(acc[r] + w.c1_b[co]);
+            }
+        }
+    }
+    if (tid < CH) {  // extra slots of the conv1 planes: no ring in block 1, slot P+1 is the zero pad
+        z0[tid * (P0 + 2) + P0] = 0.f;
+        z0[tid * (P0 + 2) + P0 + 1] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // One depthwise-separable block.  wa: pointwise weights of THIS block on entry; on exit (N < 4) the
 // loads of the next block's weights have been issued into it, so they fly across the barrier.
@@ -312,20 +418,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
         };
         // depthwise 3x3 (+bias) of this step's channel at this lane's column -> one MFMA B operand element
         auto dw_eval = [&](const Taps& tp) -> float {
-            float c = tp.q2.y;                                     // bias
-            c = fmaf(tp.q0.y, tp.up, c);                           // (dh,dx) = (-1, 0)
-            c = fmaf(tp.q1.x, tp.mid, c);                          //           ( 0, 0)
-            c = fmaf(tp.q1.w, tp.dn, c);                           //           (+1, 0)
-            // The weights are the same in all 32 lanes of a half, so the column sums for the right-hand
-            // and left-hand neighbours are formed here, at the source lane, and shifted once each.
-            float to_right = tp.q0.x * tp.up;                      // what lane+1 needs: its (.., -1) taps
-            to_right = fmaf(tp.q0.w, tp.mid, to_right);
-            to_right = fmaf(tp.q1.z, tp.dn, to_right);
-            float to_left = tp.q0.z * tp.up;                       // what lane-1 needs: its (.., +1) taps
-            to_left = fmaf(tp.q1.y, tp.mid, to_left);
-            to_left = fmaf(tp.q2.x, tp.dn, to_left);
-            c = fmaf(mask_l, from_lane_below(to_right), c);
-            return fmaf(mask_r, from_lane_above(to_left), c);
+            return stencil3x3<(MFMA && !SPLIT)>(tp.q0.x, tp.q0.y, tp.q0.z, tp.q0.w, tp.q1.x, tp.q1.y, tp.q1.z, tp.q1.w, tp.q2.x,
+                                                tp.q2.y, tp.up, tp.mid, tp.dn, mask_l, mask_r);
         };
 
         if constexpr (MFMA) {
@@ -494,6 +588,197 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 block phase, two tiles per wavefront.  A wavefront evaluates the depthwise stencil of tiles 2u and
+// 2u+1 side by side, so one read of a channel's depthwise weights (3 x ds_read_b128, the largest share of this
+// kernel's LDS traffic) serves 60 positions instead of 30, and the 24 MFMAs of a k-block (2 tiles x 2 channel
+// tiles x 6 products) are issued three per channel step under the stencil of the next k-block -- about 48 cycles
+// of bf16 matrix pipe next to about 46 cycles of VALU.  Every block fits one round of the 8 wavefronts
+// (3, 5, 6, 8 tile pairs), so there is no unit loop and block 4 reduces its pool partials straight from the
+// accumulators.
+// A operands (pointwise weights of block n, k-block m: [channel tile][hi, mid, lo]) -- 24 registers per k-block.
+// They are fetched one k-block ahead from global memory (L1/L2-resident, the same bytes the f32 path loads once
+// per block) into a two-deep ring instead of being held for the whole block: that frees 48 registers.
+typedef uintx4 AFrag[2][3];
+__device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, AFrag& f) {
+    const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[ct][p] = src[((ct * 4 + m) * 3 + p) * 64];
+}
+
+// On entry af[0] holds k-block 0 of this block (fetched during the previous phase); on exit (N < 4) the fetch of
+// the next block's k-block 0 into af[0] is in flight.
+template <int N>
+__device__ __forceinline__ void block_phase_pair(const DscnnWeights& w, float* lds, int tid, AFrag (&af)[2]) {
+    using G = Blk<N>;
+    constexpr int PAIRS = (G::TILES + 1) / 2;
+    static_assert(PAIRS <= NW, "one tile pair per wavefront");
+    static_assert(N < 4 || PAIRS == NW, "block 4: every wavefront writes its pool partials");
+    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+    float* zout = lds + G::OFF_OUT;
+    const float* dwtab = lds + OFF_DWTAB + G::BUF * 768;
+    const float* pwb = lds + OFF_PWB + G::BUF * 64;
+    float* poolbuf = lds + OFF_POOLBUF;
+
+    BlockTables next_tables;
+    if constexpr (N < 4) {
+        fetch_block_tables(w, N + 1, tid, next_tables);
+        if (tid < CH) {
+            zout[tid * G::SOUT + G::POUT] = relu(pwb[tid]);
+            zout[tid * G::SOUT + G::POUT + 1] = 0.f;
+        }
+    }
+    if (wv >= PAIRS) {  // no unit in this block: fetch the next block's operands and tables, then wait at the barrier
+        if constexpr (N < 4) {
+            load_afrag(w, N + 1, 0, lane, af[0]);
+            store_block_tables(lds, N + 1, tid, next_tables);
+        }
+        return;
+    }
+
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;
+    // per tile: output position of this lane's column, stencil masks, own-column tap addresses
+    int pos[2], tlo[2][3], thi[2][3];
+    float mask_l[2], mask_r[2];
+    bool valid[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        pos[t] = (2 * wv + t) * TW - 1 + col;
+        valid[t] = col >= 1 && col <= TW && pos[t] < G::POUT;
+        const int posc = pos[t] < 0 ? 0 : (pos[t] < G::POUT ? pos[t] : G::POUT - 1);
+        const int h = posc / G::W, x = posc % G::W;
+        mask_l[t] = x > 0 ? 1.f : 0.f;
+        mask_r[t] = x < G::W - 1 ? 1.f : 0.f;
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh) {
+            const int o = G::RING ? 1 : 0;
+            const int hh = h + dh - o, xx = x - o;
+            const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
+            const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
+            const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
+            tlo[t][dh + 1] = G::OFF_IN + a + half * 8 * G::SIN;
+            thi[t][dh + 1] = tlo[t][dh + 1] + 32 * G::SIN;
+            asm volatile("" : "+v"(tlo[t][dh + 1]));
+            asm volatile("" : "+v"(thi[t][dh + 1]));
+        }
+    }
+
+    floatx16 acc[2][2];  // [tile][channel tile]
+    {
+        const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b0 = bias4[2 * q], b1 = bias4[8 + 2 * q];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[t][0][4 * q + 0] = b0.x; acc[t][0][4 * q + 1] = b0.y; acc[t][0][4 * q + 2] = b0.z; acc[t][0][4 * q + 3] = b0.w;
+                acc[t][1][4 * q + 0] = b1.x; acc[t][1][4 * q + 1] = b1.y; acc[t][1][4 * q + 2] = b1.z; acc[t][1][4 * q + 3] = b1.w;
+            }
+        }
+    }
+
+    struct Wts {
+        float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
+    };
+    struct Taps {
+        float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
+    };
+    auto cs_of = [](int s) { return 16 * (s >> 3) + (s & 7); };  // channel of step s minus the half's offset 8*half
+    auto wts_load = [&](int s, Wts& wt) {
+        wt.q0 = dwt4[cs_of(s) * 3 + 0];
+        wt.q1 = dwt4[cs_of(s) * 3 + 1];
+        wt.q2 = dwt4[cs_of(s) * 3 + 2];
+    };
+    auto taps_load = [&](int t, int s, Taps& tp) {
+        const int cs = cs_of(s);
+        const int* ta = cs < 32 ? tlo[t] : thi[t];
+        const int o = (cs & 31) * G::SIN;
+        tp.up = lds[ta[0] + o];
+        tp.mid = lds[ta[1] + o];
+        tp.dn = lds[ta[2] + o];
+    };
+    auto dw_eval = [&](int t, const Wts& wt, const Taps& tp) -> float {
+        return stencil3x3(wt.q0.x, wt.q0.y, wt.q0.z, wt.q0.w, wt.q1.x, wt.q1.y, wt.q1.z, wt.q1.w, wt.q2.x, wt.q2.y, tp.up, tp.mid,
+                          tp.dn, mask_l[t], mask_r[t]);
+    };
+
+    float y[2][8];     // B operand elements of the running k-block
+    uintx4 fr[2][3];   // split B operands of the previous k-block: [tile][hi, mid, lo]
+    // i-th of the 24 MFMAs of k-block m; consecutive ones go to different accumulators
+    auto product = [&](int m, int i) {
+        const int t = i & 1, ct = (i >> 1) & 1, q = i >> 2;
+        const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;               // weight piece
+        const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);   // activation piece
+        acc[t][ct] = mfma_bf16(af[m & 1][ct][pa], fr[t][pb], acc[t][ct]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    Wts wt[2];
+    Taps tp[2][2];  // [tile][stage]
+    wts_load(0, wt[0]);
+    taps_load(0, 0, tp[0][0]);
+    taps_load(1, 0, tp[1][0]);
+    wts_load(1, wt[1]);
+    taps_load(0, 1, tp[0][1]);
+    taps_load(1, 1, tp[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int m = s >> 3, j = s & 7, cur = s & 1;
+        if (m > 0) product(m - 1, 3 * j);
+        y[0][j] = dw_eval(0, wt[cur], tp[0][cur]);
+        if (s + 2 < 32) taps_load(0, s + 2, tp[0][cur]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m > 0) product(m - 1, 3 * j + 1);
+        y[1][j] = dw_eval(1, wt[cur], tp[1][cur]);
+        if (s + 2 < 32) {
+            taps_load(1, s + 2, tp[1][cur]);
+            wts_load(s + 2, wt[cur]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (m > 0) product(m - 1, 3 * j + 2);
+        if (j == 7) {
+            // the products of k-block m-1 are done: its ring slot takes k-block m+1 (or the next block's first)
+            if (m < 3)
+                load_afrag(w, N, m + 1, lane, af[(m + 1) & 1]);
+            else if (N < 4)
+                load_afrag(w, N + 1, 0, lane, af[0]);
+            split3(y[0], fr[0][0], fr[0][1], fr[0][2]);
+            split3(y[1], fr[1][0], fr[1][1], fr[1][2]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) product(3, i);
+
+    if constexpr (N < 4) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (valid[t]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    zout[row_of(r, half) * G::SOUT + pos[t]] = relu(acc[t][0][r]);
+                    zout[(32 + row_of(r, half)) * G::SOUT + pos[t]] = relu(acc[t][1][r]);
+                }
+            }
+        }
+        store_block_tables(lds, N + 1, tid, next_tables);
+    } else {
+        // global average pool, part 1: sum this wavefront's 60 positions per channel (DPP, no LDS round trips)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (valid[0] ? relu(acc[0][ct][r]) : 0.f) + (valid[1] ? relu(acc[1][ct][r]) : 0.f);
+                const float sum = half_wave_sum_to_last_lane(v);
+                if (col == 31) poolbuf[wv * CH + ct * 32 + row_of(r, half)] = sum;
+            }
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
@@ -520,9 +805,19 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 0: start
 
     // ---- phase 0: weight loads in flight, MFCC map -> zero-padded [103][14] in LDS ------------------
-    float a1[50];        // conv1 weights of this wave's output-channel tile (MFMA A operands)
-    PwOperands<MODE> wa;  // pointwise weights of the running block
-    if constexpr (MFMA) {
+    constexpr bool SPLIT = MODE >= 4;
+    float a1[SPLIT ? 1 : 50];       // conv1 weights of this wave's output-channel tile (f32 MFMA A operands)
+    uintx4 c1f[SPLIT ? 7 : 1][3];   // the same as bf16 pieces (split path)
+    PwOperands<MODE> wa;            // pointwise weights of the running block (whole-block residency)
+    AFrag af[2];                    // ... or a ring of two k-blocks (tile-pair path)
+    constexpr bool PAIR = MODE == 5;
+    if constexpr (SPLIT) {
+        const uintx4* src = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(wv & 1) * (7 * 3 * 64) + lane;
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) c1f[kb][p] = src[(kb * 3 + p) * 64];
+    } else if constexpr (MFMA) {
         const int half = lane >> 5, col = lane & 31, ct = wv & 1;
 #pragma unroll
         for (int s = 0; s < 50; ++s) a1[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
@@ -555,7 +850,16 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     __syncthreads();
     stamp();  // 1: features staged
 
-    conv1_phase<MFMA>(w, lds, tid, a1);
+    if constexpr (SPLIT) {
+        conv1_phase_split(w, lds, tid, c1f);
+        // the conv1 operands are dead: block 1's fly across the barrier
+        if constexpr (PAIR)
+            load_afrag(w, 1, 0, lane, af[0]);
+        else
+            load_pointwise<MODE>(w, 1, lane, wa);
+    } else {
+        conv1_phase<MFMA>(w, lds, tid, a1);
+    }
     stamp();  // 2: conv1 units of wave 0 done
     __syncthreads();
     stamp();  // 3: conv1 barrier
@@ -565,7 +869,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         a += CH * P0;
     }
 
-    block_phase<1, MODE>(w, lds, tid, wa);
+    if constexpr (MODE == 5)
+        block_phase_pair<1>(w, lds, tid, af);
+    else
+        block_phase<1, MODE>(w, lds, tid, wa);
     stamp();  // 4: block 1 units of wave 0 done
     __syncthreads();
     stamp();  // 5: block 1 barrier
@@ -574,7 +881,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z1 + (i / Blk<1>::POUT) * Blk<1>::SOUT + i % Blk<1>::POUT];
         a += CH * Blk<1>::POUT;
     }
-    block_phase<2, MODE>(w, lds, tid, wa);
+    if constexpr (MODE == 5)
+        block_phase_pair<2>(w, lds, tid, af);
+    else
+        block_phase<2, MODE>(w, lds, tid, wa);
     stamp();  // 6
     __syncthreads();
     stamp();  // 7
@@ -583,7 +893,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z2 + (i / Blk<2>::POUT) * Blk<2>::SOUT + i % Blk<2>::POUT];
         a += CH * Blk<2>::POUT;
     }
-    block_phase<3, MODE>(w, lds, tid, wa);
+    if constexpr (MODE == 5)
+        block_phase_pair<3>(w, lds, tid, af);
+    else
+        block_phase<3, MODE>(w, lds, tid, wa);
     stamp();  // 8
     __syncthreads();
     stamp();  // 9
@@ -592,7 +905,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z3 + (i / Blk<3>::POUT) * Blk<3>::SOUT + i % Blk<3>::POUT];
         a += CH * Blk<3>::POUT;
     }
-    block_phase<4, MODE>(w, lds, tid, wa);
+    if constexpr (MODE == 5)
+        block_phase_pair<4>(w, lds, tid, af);
+    else
+        block_phase<4, MODE>(w, lds, tid, wa);
     stamp();  // 10
     __syncthreads();
     stamp();  // 11
@@ -652,7 +968,8 @@ hipError_t dscnn_init_device() {
     const int lds = LDS_FLOATS * (int)sizeof(float);
     const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -671,6 +988,7 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
         case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 4: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<4>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 5: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<5>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
     }

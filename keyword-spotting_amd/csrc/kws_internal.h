@@ -48,6 +48,7 @@ struct FrontendTables {
     const float* mel_rw;       // [8][64]    rising-edge weights of the chunk's bins (0 beyond its length)
     const float* mel_fw;       // [8][64]    falling-edge weights
     const uint32_t* mel_gather;// [64]       per filter: r0 | nr<<8 | f0<<16 | nf<<24  (chunk ranges)
+    const int* mel_slot;       // [256]      power-buffer slot of bin k = 8*chunk(k) + (k - first bin of the chunk)
     const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
 };
 
@@ -57,6 +58,7 @@ struct MelHost {
     std::vector<int> k0;               // 64
     std::vector<float> rw, fw;         // 8*64 each, [i][lane]
     std::vector<uint32_t> gather;      // 64
+    std::vector<int> slot;             // nfft/2 (bin 256 belongs to no filter)
     int n_chunks = 0;
 };
 bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::string& err);
@@ -98,6 +100,7 @@ struct DscnnWeights {
     const float* pw_w;     // [4][64][64] pointwise transposed: [cin][cout]
     const float* pw_b;     // [4][64]
     const uint32_t* pw_split;  // [4][ct 2][m 4][piece 3][lane 64][4]  pointwise weights as bf16 hi/mid/lo MFMA A operands
+    const uint32_t* c1_split;  // [ct 2][kb 7][piece 3][lane 64][4]    conv1 weights, same format (K order: see kws_dscnn.hip)
     const float* fc_w;     // [C][64]
     const float* fc_b;     // [C]
     int num_classes;

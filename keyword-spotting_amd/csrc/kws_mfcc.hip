@@ -66,14 +66,20 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
     v[7] = csub(e1, e3);
 }
 
-// Complex row strides of the two register<->LDS exchanges.  72 (64 + 8) makes the strided column gather of
-// the first exchange conflict-free for ds_read_b64; 66 puts the sixteen 64-byte row segments that one
-// ds_read_b128 lane group fetches in the second exchange on sixteen different 16-byte slots.
-constexpr int XROW1 = 72, XROW2 = 66;
+// Complex row stride of the two register<->LDS exchanges.  72 (64 + 8) makes the strided column gather of the
+// first exchange conflict-free for ds_read_b64; in the second exchange the column index is additionally XORed
+// with 2*(k1 & 3), which makes its ds_write_b64 conflict-free while the gather stays four aligned ds_read_b128
+// (LDS-array cycles per tools/lds_model.py: 48 for the exchange, the minimum).
+constexpr int XROW = 72;
 
-// Per-wavefront LDS scratch (bytes): exchange / spectrum buffer, then the log-mel vectors.  The power
-// spectrum and the chunk partials reuse the exchange buffer once the spectrum has been read.
-constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_CBUF = 2112, SCR_LBUF = 4608, SCR_BYTES = 4608 + 512;
+// Per-wavefront LDS scratch (bytes): exchange / spectrum / power buffer, chunk partials, log-mel vectors.
+constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_CBUF = 4608, SCR_LBUF = 4608 + 1024, SCR_BYTES = 4608 + 1024 + 512;
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+// LDS byte address of a pointer into shared memory (for hand-written ds_* instructions)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
 
 // LDS instructions of one wavefront execute in order, so data written by one lane is visible to a later
 // read of another lane of the SAME wavefront without s_barrier or s_waitcnt; only the compiler has to keep
@@ -90,7 +96,7 @@ __device__ __forceinline__ int zswz(int k) { return k ^ ((k >> 3) & 7); }
 // 512-point complex FFT across one wavefront.
 //   in : lane l holds z[64*n1 + l] in v[n1]
 //   out: lane l (k1 = l>>3, c = l&7) holds Z[k1 + 8*c + 64*d] in v[d]
-// xbuf: 8*XROW1 complex of LDS private to the wavefront; t1[i] = W512^(lane*i); tw2 = LDS table [8][8] of
+// xbuf: 8*XROW complex of LDS private to the wavefront; t1[i] = W512^(lane*i); tw2 = LDS table [8][8] of
 // W64^(q*i).
 __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], const cf* tw2, int lane) {
     const int k1 = lane >> 3, q = lane & 7;
@@ -98,21 +104,46 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
 #pragma unroll
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], t1[i]);  // W512^(lane*k1)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xbuf[i * XROW1 + lane] = v[i];
+    for (int i = 0; i < 8; ++i) xbuf[i * XROW + lane] = v[i];
     wave_lds_order();
-    // lane (k1, b=q): gather y[k1][8a + b], a = 0..7
-#pragma unroll
-    for (int a = 0; a < 8; ++a) v[a] = xbuf[k1 * XROW1 + 8 * a + q];
+    // lane (k1, b=q): gather y[k1][8a + b], a = 0..7.  Eight ds_read_b64 by hand: the compiler would pair them
+    // into ds_read2_b64, which moves the same bytes in twice the LDS-array cycles.
+    {
+        floatx2 r0, r1, r2, r3, r4, r5, r6, r7;
+        asm volatile(
+            "ds_read_b64 %0, %8\n\t"
+            "ds_read_b64 %1, %8 offset:64\n\t"
+            "ds_read_b64 %2, %8 offset:128\n\t"
+            "ds_read_b64 %3, %8 offset:192\n\t"
+            "ds_read_b64 %4, %8 offset:256\n\t"
+            "ds_read_b64 %5, %8 offset:320\n\t"
+            "ds_read_b64 %6, %8 offset:384\n\t"
+            "ds_read_b64 %7, %8 offset:448\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+            : "v"(lds_addr(xbuf + k1 * XROW + q))
+            : "memory");
+        v[0] = {r0.x, r0.y}; v[1] = {r1.x, r1.y}; v[2] = {r2.x, r2.y}; v[3] = {r3.x, r3.y};
+        v[4] = {r4.x, r4.y}; v[5] = {r5.x, r5.y}; v[6] = {r6.x, r6.y}; v[7] = {r7.x, r7.y};
+    }
     wave_lds_order();
     dft8(v);  // over a -> c
 #pragma unroll
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], tw2[q * 8 + i]);  // W64^(b*c)
+    const int sw = k1 & 3;  // column swizzle of the second exchange, in units of complex pairs
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xbuf[k1 * XROW2 + 8 * c + q] = v[c];
+    for (int c = 0; c < 8; ++c) xbuf[k1 * XROW + 8 * c + (q ^ (2 * sw))] = v[c];
     wave_lds_order();
-    // lane (k1, c=q): gather u[k1][c][b], b = 0..7 (contiguous)
+    // lane (k1, c=q): gather u[k1][c][b], b = 0..7; the pair (2p, 2p+1) sits in pair slot p ^ sw
+    {
+        const float4* row4 = reinterpret_cast<const float4*>(xbuf + k1 * XROW + 8 * q);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) v[b] = xbuf[k1 * XROW2 + 8 * q + b];
+        for (int pr = 0; pr < 4; ++pr) {
+            const float4 f = row4[pr ^ sw];
+            v[2 * pr] = {f.x, f.y};
+            v[2 * pr + 1] = {f.z, f.w};
+        }
+    }
     wave_lds_order();
     dft8(v);  // over b -> d
 }
@@ -156,8 +187,10 @@ __device__ __forceinline__ void fill_tw2(const float2* __restrict__ tw, cf* tw2,
 // nza / nzb: whether frame a / b has any non-zero sample.  An all-zero frame must give exactly 0 (the
 // reference then floors to eps); computed through the packed transform it would instead pick up the
 // partner frame's float32 rounding noise (-140 dB), so it is forced.
+// pslot[j]: power-buffer slot of bin lane + 64j (the MFCC path stores the bins grouped by mel chunk; the
+// spectrum operators pass the identity); slot256: where bin 256 goes, or -1 to drop it.
 __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* pbuf, int lane, int power, bool nza,
-                                            bool nzb, float& ea, float& eb) {
+                                            bool nzb, const int (&pslot)[4], int slot256, float& ea, float& eb) {
     const int k1 = lane >> 3, q = lane & 7;
 #pragma unroll
     for (int d = 0; d < 8; ++d) zbuf[zswz(k1 + 8 * q + 64 * d)] = v[d];
@@ -185,7 +218,7 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         }
         pa = nza ? pa : 0.f;
         pb = nzb ? pb : 0.f;
-        pbuf[lane + 64 * j] = make_float2(pa, pb);
+        pbuf[pslot[j]] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
     }
@@ -198,7 +231,7 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         }
         pa = nza ? pa : 0.f;
         pb = nzb ? pb : 0.f;
-        pbuf[256] = make_float2(pa, pb);
+        if (slot256 >= 0) pbuf[slot256] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
     }
@@ -214,48 +247,70 @@ __device__ __forceinline__ float to_unit(float s) { return s; }
 
 // Views of the LDS a wavefront needs for one frame pair: its private scratch and the workgroup tables.
 struct PairScratch {
-    cf* xbuf;          // 8*XROW1 complex: exchange buffer / spectrum / power spectrum
+    cf* xbuf;          // 8*XROW complex: exchange buffer / spectrum / power spectrum
     float2* pbuf;      // aliases xbuf
     float4* cbuf;      // chunk partials
     float* lbuf;       // 2 x 64 centred log-mel values
     const float* dctb; // [numcep][nfp]
-    const float* melw; // [16][64]
     const cf* tw2;     // [8][8]
     int nfp;
 };
+
+// Per-lane constants of the sparse mel stage: lane c owns chunk c (<= 8 bins of one inter-edge segment).
+struct MelLane {
+    float rw[MEL_CHUNK], fw[MEL_CHUNK];  // rising / falling weights of the chunk's bins (0 beyond its length)
+    int pslot[4];                        // power-buffer slots of bins lane + 64j
+    uint32_t gth;                        // filter `lane`: chunk ranges r0 | nr<<8 | f0<<16 | nf<<24
+};
+__device__ __forceinline__ void load_mel_lane(const FrontendTables& t, int lane, MelLane& m) {
+#pragma unroll
+    for (int i = 0; i < MEL_CHUNK; ++i) {
+        m.rw[i] = t.mel_rw[i * 64 + lane];
+        m.fw[i] = t.mel_fw[i * 64 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m.pslot[j] = t.mel_slot[lane + 64 * j];
+    m.gth = t.mel_gather[lane];
+}
 
 // One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
 // FFT -> split -> power -> sparse mel -> log -> DCT x lifter, c0 = log(frame energy).
 // out_a / out_b: rows of numcep floats for frame a / b (out_b is not touched when has_b is false).
 __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
-                                          const PairScratch& sc, const cf (&t1)[8], int mk0, uint32_t gth, int lane,
+                                          const PairScratch& sc, const cf (&t1)[8], const MelLane& ml, int lane,
                                           float* __restrict__ out_a, float* __restrict__ out_b) {
     cf* xbuf = sc.xbuf;
     float2* pbuf = sc.pbuf;
     float4* cbuf = sc.cbuf;
     float* lbuf = sc.lbuf;
     const float* dctb = sc.dctb;
-    const float* melw = sc.melw;
     const cf* tw2 = sc.tw2;
+    const uint32_t gth = ml.gth;
     const int nfp = sc.nfp;
     fft512(v, xbuf, t1, tw2, lane);
 
     float ea, eb;
-    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ea, eb);
+    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, ea, eb);
     ea = wave_sum(ea);
     eb = wave_sum(eb);
 
-    // sparse mel: this lane's chunk of <= 8 bins
+    // sparse mel: this lane's chunk of <= 8 bins is one contiguous 64-byte run of the power buffer (four
+    // conflict-free ds_read_b128); slots past the chunk's length hold stale finite values and meet zero weights
     float ra = 0.f, fa_ = 0.f, rb = 0.f, fb_ = 0.f;
+    {
+        const float4* pc = reinterpret_cast<const float4*>(pbuf + lane * MEL_CHUNK);
 #pragma unroll
-    for (int i = 0; i < MEL_CHUNK; ++i) {
-        const int k = min(mk0 + i, NBINS - 1);
-        const float2 pw = pbuf[k];
-        const float rwi = melw[i * 64 + lane], fwi = melw[(8 + i) * 64 + lane];
-        ra = fmaf(rwi, pw.x, ra);
-        fa_ = fmaf(fwi, pw.x, fa_);
-        rb = fmaf(rwi, pw.y, rb);
-        fb_ = fmaf(fwi, pw.y, fb_);
+        for (int h = 0; h < MEL_CHUNK / 2; ++h) {
+            const float4 pw = pc[h];  // (bin 2h: frame a, frame b), (bin 2h+1: frame a, frame b)
+            ra = fmaf(ml.rw[2 * h], pw.x, ra);
+            fa_ = fmaf(ml.fw[2 * h], pw.x, fa_);
+            rb = fmaf(ml.rw[2 * h], pw.y, rb);
+            fb_ = fmaf(ml.fw[2 * h], pw.y, fb_);
+            ra = fmaf(ml.rw[2 * h + 1], pw.z, ra);
+            fa_ = fmaf(ml.fw[2 * h + 1], pw.z, fa_);
+            rb = fmaf(ml.rw[2 * h + 1], pw.w, rb);
+            fb_ = fmaf(ml.fw[2 * h + 1], pw.w, fb_);
+        }
     }
     wave_lds_order();
     cbuf[lane] = make_float4(ra, fa_, rb, fb_);
@@ -323,8 +378,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     // workgroup-shared part (every offset a multiple of 16 bytes)
     const int nfp = (p.nfilt + 3) & ~3;                        // DCT rows padded to float4
     float* dctb = reinterpret_cast<float*>(smem);              // [numcep][nfp]
-    float* melw = dctb + p.numcep * nfp;                       // [16][64]: rw[0..7], fw[0..7] per lane
-    cf* tw2 = reinterpret_cast<cf*>(melw + 16 * 64);           // [8][8]
+    cf* tw2 = reinterpret_cast<cf*>(dctb + ((p.numcep * nfp + 3) & ~3));  // [8][8]
     float* ybuf = reinterpret_cast<float*>(tw2 + 64);          // chunk_samples floats (padded to 8)
     unsigned char* scr0 = reinterpret_cast<unsigned char*>(ybuf + ((p.chunk_samples + 7) & ~7));
 
@@ -371,20 +425,19 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         const int r = i / nfp, j = i % nfp;
         dctb[i] = j < p.nfilt ? t.dct[r * p.nfilt + j] : 0.f;
     }
-    for (int i = tid; i < 16 * 64; i += MFCC_THREADS) melw[i] = i < 8 * 64 ? t.mel_rw[i] : t.mel_fw[i - 8 * 64];
     fill_tw2(t.twiddle, tw2, tid);
 
     // ---- per-lane constants -----------------------------------------------------------------------
     cf t1[8];
     load_twiddles(t.twiddle, lane, t1);
-    const int mk0 = t.mel_k0[lane];
-    const uint32_t gth = t.mel_gather[lane];
+    MelLane ml;
+    load_mel_lane(t, lane, ml);
     __syncthreads();  // the only workgroup barrier: staged samples and tables are visible to all waves
 
     unsigned char* scr = scr0 + wv * SCR_BYTES;
     const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
                             reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
-                            dctb, melw, tw2, nfp};
+                            dctb, tw2, nfp};
 
     for (int pr = wv; pr < MFCC_FRAMES_PER_WG / 2; pr += MFCC_WAVES) {
         const int fa = f0 + 2 * pr;
@@ -406,7 +459,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         }
         nza = __any(nza);
         nzb = __any(nzb);
-        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, mk0, gth, lane,
+        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
                   out + ((size_t)clip * p.num_frames + fa) * p.numcep,
                   out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
         wave_lds_order();
@@ -448,7 +501,7 @@ __global__ void kws_framesig_f32_kernel(const float* __restrict__ in, int n, int
 __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, const float* __restrict__ frames,
                                                              int num_frames, int frame_len, int power,
                                                              float* __restrict__ spec) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SCR_BYTES + 512];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SCR_BYTES + 512];  // scratch + tw2
     cf* xbuf = reinterpret_cast<cf*>(smem + SCR_XBUF);
     float2* pbuf = reinterpret_cast<float2*>(smem + SCR_PBUF);
     cf* tw2 = reinterpret_cast<cf*>(smem + SCR_BYTES);
@@ -476,7 +529,8 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
     nzb = __any(nzb);
     fft512(v, xbuf, t1, tw2, lane);
     float ea, eb;
-    split_power(v, xbuf, pbuf, lane, power, nza, nzb, ea, eb);
+    const int ident[4] = {lane, lane + 64, lane + 128, lane + 192};
+    split_power(v, xbuf, pbuf, lane, power, nza, nzb, ident, 256, ea, eb);
     for (int k = lane; k < NBINS; k += 64) {
         const float2 pw = pbuf[k];
         spec[(size_t)fa * NBINS + k] = pw.x;
@@ -498,8 +552,7 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfp = (p.nfilt + 3) & ~3;
     float* dctb = reinterpret_cast<float*>(smem);
-    float* melw = dctb + p.numcep * nfp;
-    cf* tw2 = reinterpret_cast<cf*>(melw + 16 * 64);
+    cf* tw2 = reinterpret_cast<cf*>(dctb + ((p.numcep * nfp + 3) & ~3));
     unsigned char* scr = reinterpret_cast<unsigned char*>(tw2 + 64);
     const int lane = threadIdx.x;
     const int sa = 2 * blockIdx.x, sb = sa + 1;
@@ -512,12 +565,11 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
         const int r = i / nfp, j = i % nfp;
         dctb[i] = j < p.nfilt ? t.dct[r * p.nfilt + j] : 0.f;
     }
-    for (int i = lane; i < 16 * 64; i += 64) melw[i] = i < 8 * 64 ? t.mel_rw[i] : t.mel_fw[i - 8 * 64];
     fill_tw2(t.twiddle, tw2, lane);
     cf t1[8];
     load_twiddles(t.twiddle, lane, t1);
-    const int mk0 = t.mel_k0[lane];
-    const uint32_t gth = t.mel_gather[lane];
+    MelLane ml;
+    load_mel_lane(t, lane, ml);
 
     // sample n (absolute) of stream s: current hop -> d_hop, recent past -> ring, before the stream began -> 0
     auto sample = [&](int s, long n) -> float {
@@ -554,9 +606,9 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
     if (frame_ok) {
         const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
                                 reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
-                                dctb, melw, tw2, nfp};
+                                dctb, tw2, nfp};
         const int row = (int)(fidx % p.num_frames);
-        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, mk0, gth, lane,
+        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
                   feat_ring + ((size_t)sa * p.num_frames + row) * p.numcep,
                   feat_ring + ((size_t)sb * p.num_frames + row) * p.numcep);
     }
@@ -601,7 +653,7 @@ __global__ void kws_augment_i16_kernel(const int16_t* __restrict__ wav, int B, i
 // ------------------------------------------------------------------------------------------------
 size_t mfcc_lds_bytes(const FrontendParams& p) {
     const int nfp = (p.nfilt + 3) & ~3;
-    return sizeof(float) * (size_t)(p.numcep * nfp + 16 * 64 + 2 * 64 + ((p.chunk_samples + 7) & ~7)) +
+    return sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64 + ((p.chunk_samples + 7) & ~7)) +
            (size_t)MFCC_WAVES * SCR_BYTES;
 }
 
@@ -632,7 +684,7 @@ hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const Fronten
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
                                int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, const int* d_hops) {
     const int nfp = (p.nfilt + 3) & ~3;
-    const size_t lds = sizeof(float) * (size_t)(p.numcep * nfp + 16 * 64 + 2 * 64) + SCR_BYTES;
+    const size_t lds = sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES;
     hipLaunchKernelGGL(kws_stream_frame_kernel, dim3((n_streams + 1) / 2), dim3(64), lds, s, p, t, d_hop, n_streams,
                        d_pcm_ring, ring_len, d_feat_ring, d_hops);
     return hipGetLastError();
