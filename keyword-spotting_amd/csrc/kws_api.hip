@@ -538,14 +538,14 @@ int kws_set_pointwise_math(kws_ctx* c, int math) {
 
 int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                           int use_mfma) {
-    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16 && use_mfma != 5)
+    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16)
         return fail(c, KWS_EINVAL, "kws_forward_debug_f32: use_mfma must be 0, KWS_PW_F32 or KWS_PW_SPLIT_BF16");
     return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma, "kws_forward_debug_f32");
 }
 
 int kws_forward_stamps_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode) {
     if (!d_stamps) return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: d_stamps is NULL");
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6)
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 6)
         return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: unknown kernel variant");
     return forward_impl(c, d_feat, B, d_logits, nullptr, nullptr, mode, "kws_forward_stamps_f32",
                         reinterpret_cast<unsigned long long*>(d_stamps));

@@ -157,38 +157,40 @@ __device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, c
     if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b;
 }
 
-// Pointwise weights of the running block as MFMA A operands, held in registers for the whole block.
-//   f32 path   (32x32x2 f32):   wa[ct][s]   = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)]
-//   split path (32x32x16 bf16): f[ct][m][p] = piece p (0 hi, 1 mid, 2 lo) of W[cout = ct*32 + (l&31)][cin = 16m + 8(l>>5) + j],
-//                               j = 0..7 -- eight bf16 per lane, pre-split on the host (exactly: hi + mid + lo == W)
+// Pointwise weights of the running block as MFMA A operands.
+//   f32 path   (32x32x2 f32):   wa[ct][s] = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)], held for the whole block.
+//   split path (32x32x16 bf16): piece p (0 hi, 1 mid, 2 lo) of W[cout = ct*32 + (l&31)][cin = 16m + 8(l>>5) + j],
+//     j = 0..7 -- eight bf16 per lane and (ct, m, p), pre-split on the host (exactly: hi + mid + lo == W).  Only
+//     two k-blocks m are in registers at a time: ring[m & 1] is fetched one k-block ahead from global memory
+//     (L1/L2-resident; the same bytes per block as the f32 path loads), which frees 48 registers.
+typedef uintx4 AFrag[2][3];  // [channel tile][piece] of one k-block
 template <bool SPLIT>
 struct PwRegs {
     float wa[2][32];
 };
 template <>
 struct PwRegs<true> {
-    uintx4 f[2][4][3];
+    AFrag ring[2];
 };
 template <int MODE>
 using PwOperands = PwRegs<(MODE >= 4)>;
-template <int MODE>
-__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwOperands<MODE>& o) {
-    if constexpr (MODE >= 4) {
-        const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
+__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) {
+    const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) o.f[ct][m][p] = src[((ct * 4 + m) * 3 + p) * 64];
-    } else {
-        const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[2 * s * CH + ct * 32];
-    }
+        for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[2 * s * CH + ct * 32];
 }
+__device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, AFrag& f) {
+    const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[ct][p] = src[((ct * 4 + m) * 3 + p) * 64];
+}
+// first operands of block n: the whole block (f32) or its k-block 0 (split)
+__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) { load_pointwise(w, n, lane, o); }
+__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<true>& o) { load_afrag(w, n, 0, lane, o.ring[0]); }
 
 // Exact three-way split of eight f32 values into bf16 pieces (y == hi + mid + lo, each piece the top 16 bits of
 // the running remainder), packed as MFMA B operands.  bf16 x bf16 products are exact in the matrix core's f32
@@ -335,8 +337,9 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// One depthwise-separable block.  wa: pointwise weights of THIS block on entry; on exit (N < 4) the
-// loads of the next block's weights have been issued into it, so they fly across the barrier.
+// One depthwise-separable block.  pwo: pointwise operands of THIS block on entry (f32: all of them; split:
+// k-block 0 in ring[0]); on exit (N < 4) the loads of the next block's have been issued into it, so they fly
+// across the barrier.
 // MODE: 0 = pointwise GEMM on the VALU (cross-check of the MFMA operand mappings), 1 = f32 MFMA,
 // 4 = split-bf16 MFMA (product path), 2 / 3 = timing ablations of mode 1 (matrix core only / stencil only;
 // wrong results by construction).
@@ -448,9 +451,9 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
                     const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
                     if (ct == 0)
-                        acc0 = mfma_bf16(pwo.f[0][m][pa], b, acc0);
+                        acc0 = mfma_bf16(pwo.ring[m & 1][0][pa], b, acc0);
                     else
-                        acc1 = mfma_bf16(pwo.f[1][m][pa], b, acc1);
+                        acc1 = mfma_bf16(pwo.ring[m & 1][1][pa], b, acc1);
                     __builtin_amdgcn_sched_barrier(0);
                 };
 #pragma unroll
@@ -468,6 +471,17 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                         if (s + 2 < 32) dw_load(s + 2, tp);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (j == 6) {
+                        // the products of k-block m-1 are done: its ring slot takes k-block m+1, or k-block 0 of
+                        // this wave's next unit / of the next block
+                        if (m < 3)
+                            load_afrag(w, N, m + 1, lane, pwo.ring[(m + 1) & 1]);
+                        else if (t + NW < G::TILES)
+                            load_afrag(w, N, 0, lane, pwo.ring[0]);
+                        else if (N < 4)
+                            load_afrag(w, N < 4 ? N + 1 : N, 0, lane, pwo.ring[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (j == 7) {
                         split3(y, bh, bm, bl);
                         __builtin_amdgcn_sched_barrier(0);
@@ -530,12 +544,14 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             };
             // this wave's last unit: the A operands are dead, so the next block's are fetched now and the
             // loads fly under the epilogue, the barrier and the next prologue
-            if (N < 4 && t + NW >= G::TILES) {
-                __builtin_amdgcn_sched_barrier(0);  // not before the last MFMA has read the old operands
-                if constexpr (N < 4) load_pointwise<MODE>(w, N + 1, lane, pwo);
-                __builtin_amdgcn_sched_barrier(0);
-                epilogue();
-                break;
+            if constexpr (!SPLIT) {
+                if (N < 4 && t + NW >= G::TILES) {
+                    __builtin_amdgcn_sched_barrier(0);  // not before the last MFMA has read the old operands
+                    if constexpr (N < 4) load_pointwise(w, N + 1, lane, pwo);
+                    __builtin_amdgcn_sched_barrier(0);
+                    epilogue();
+                    break;
+                }
             }
             epilogue();
         } else {
@@ -571,7 +587,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
-            if (wv >= G::TILES) load_pointwise<MODE>(w, N + 1, lane, pwo);  // waves without a unit in this block
+            if (wv >= G::TILES) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
         } else {
             // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips)
 #pragma unroll
@@ -587,197 +603,6 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     (void)bias4;
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// Split-bf16 block phase, two tiles per wavefront.  A wavefront evaluates the depthwise stencil of tiles 2u and
-// 2u+1 side by side, so one read of a channel's depthwise weights (3 x ds_read_b128, the largest share of this
-// kernel's LDS traffic) serves 60 positions instead of 30, and the 24 MFMAs of a k-block (2 tiles x 2 channel
-// tiles x 6 products) are issued three per channel step under the stencil of the next k-block -- about 48 cycles
-// of bf16 matrix pipe next to about 46 cycles of VALU.  Every block fits one round of the 8 wavefronts
-// (3, 5, 6, 8 tile pairs), so there is no unit loop and block 4 reduces its pool partials straight from the
-// accumulators.
-// A operands (pointwise weights of block n, k-block m: [channel tile][hi, mid, lo]) -- 24 registers per k-block.
-// They are fetched one k-block ahead from global memory (L1/L2-resident, the same bytes the f32 path loads once
-// per block) into a two-deep ring instead of being held for the whole block: that frees 48 registers.
-typedef uintx4 AFrag[2][3];
-__device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, AFrag& f) {
-    const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) f[ct][p] = src[((ct * 4 + m) * 3 + p) * 64];
-}
-
-// On entry af[0] holds k-block 0 of this block (fetched during the previous phase); on exit (N < 4) the fetch of
-// the next block's k-block 0 into af[0] is in flight.
-template <int N>
-__device__ __forceinline__ void block_phase_pair(const DscnnWeights& w, float* lds, int tid, AFrag (&af)[2]) {
-    using G = Blk<N>;
-    constexpr int PAIRS = (G::TILES + 1) / 2;
-    static_assert(PAIRS <= NW, "one tile pair per wavefront");
-    static_assert(N < 4 || PAIRS == NW, "block 4: every wavefront writes its pool partials");
-    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
-    float* zout = lds + G::OFF_OUT;
-    const float* dwtab = lds + OFF_DWTAB + G::BUF * 768;
-    const float* pwb = lds + OFF_PWB + G::BUF * 64;
-    float* poolbuf = lds + OFF_POOLBUF;
-
-    BlockTables next_tables;
-    if constexpr (N < 4) {
-        fetch_block_tables(w, N + 1, tid, next_tables);
-        if (tid < CH) {
-            zout[tid * G::SOUT + G::POUT] = relu(pwb[tid]);
-            zout[tid * G::SOUT + G::POUT + 1] = 0.f;
-        }
-    }
-    if (wv >= PAIRS) {  // no unit in this block: fetch the next block's operands and tables, then wait at the barrier
-        if constexpr (N < 4) {
-            load_afrag(w, N + 1, 0, lane, af[0]);
-            store_block_tables(lds, N + 1, tid, next_tables);
-        }
-        return;
-    }
-
-    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;
-    // per tile: output position of this lane's column, stencil masks, own-column tap addresses
-    int pos[2], tlo[2][3], thi[2][3];
-    float mask_l[2], mask_r[2];
-    bool valid[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        pos[t] = (2 * wv + t) * TW - 1 + col;
-        valid[t] = col >= 1 && col <= TW && pos[t] < G::POUT;
-        const int posc = pos[t] < 0 ? 0 : (pos[t] < G::POUT ? pos[t] : G::POUT - 1);
-        const int h = posc / G::W, x = posc % G::W;
-        mask_l[t] = x > 0 ? 1.f : 0.f;
-        mask_r[t] = x < G::W - 1 ? 1.f : 0.f;
-#pragma unroll
-        for (int dh = -1; dh <= 1; ++dh) {
-            const int o = G::RING ? 1 : 0;
-            const int hh = h + dh - o, xx = x - o;
-            const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
-            const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
-            const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
-            tlo[t][dh + 1] = G::OFF_IN + a + half * 8 * G::SIN;
-            thi[t][dh + 1] = tlo[t][dh + 1] + 32 * G::SIN;
-            asm volatile("" : "+v"(tlo[t][dh + 1]));
-            asm volatile("" : "+v"(thi[t][dh + 1]));
-        }
-    }
-
-    floatx16 acc[2][2];  // [tile][channel tile]
-    {
-        const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b0 = bias4[2 * q], b1 = bias4[8 + 2 * q];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                acc[t][0][4 * q + 0] = b0.x; acc[t][0][4 * q + 1] = b0.y; acc[t][0][4 * q + 2] = b0.z; acc[t][0][4 * q + 3] = b0.w;
-                acc[t][1][4 * q + 0] = b1.x; acc[t][1][4 * q + 1] = b1.y; acc[t][1][4 * q + 2] = b1.z; acc[t][1][4 * q + 3] = b1.w;
-            }
-        }
-    }
-
-    struct Wts {
-        float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
-    };
-    struct Taps {
-        float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
-    };
-    auto cs_of = [](int s) { return 16 * (s >> 3) + (s & 7); };  // channel of step s minus the half's offset 8*half
-    auto wts_load = [&](int s, Wts& wt) {
-        wt.q0 = dwt4[cs_of(s) * 3 + 0];
-        wt.q1 = dwt4[cs_of(s) * 3 + 1];
-        wt.q2 = dwt4[cs_of(s) * 3 + 2];
-    };
-    auto taps_load = [&](int t, int s, Taps& tp) {
-        const int cs = cs_of(s);
-        const int* ta = cs < 32 ? tlo[t] : thi[t];
-        const int o = (cs & 31) * G::SIN;
-        tp.up = lds[ta[0] + o];
-        tp.mid = lds[ta[1] + o];
-        tp.dn = lds[ta[2] + o];
-    };
-    auto dw_eval = [&](int t, const Wts& wt, const Taps& tp) -> float {
-        return stencil3x3(wt.q0.x, wt.q0.y, wt.q0.z, wt.q0.w, wt.q1.x, wt.q1.y, wt.q1.z, wt.q1.w, wt.q2.x, wt.q2.y, tp.up, tp.mid,
-                          tp.dn, mask_l[t], mask_r[t]);
-    };
-
-    float y[2][8];     // B operand elements of the running k-block
-    uintx4 fr[2][3];   // split B operands of the previous k-block: [tile][hi, mid, lo]
-    // i-th of the 24 MFMAs of k-block m; consecutive ones go to different accumulators
-    auto product = [&](int m, int i) {
-        const int t = i & 1, ct = (i >> 1) & 1, q = i >> 2;
-        const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;               // weight piece
-        const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);   // activation piece
-        acc[t][ct] = mfma_bf16(af[m & 1][ct][pa], fr[t][pb], acc[t][ct]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    Wts wt[2];
-    Taps tp[2][2];  // [tile][stage]
-    wts_load(0, wt[0]);
-    taps_load(0, 0, tp[0][0]);
-    taps_load(1, 0, tp[1][0]);
-    wts_load(1, wt[1]);
-    taps_load(0, 1, tp[0][1]);
-    taps_load(1, 1, tp[1][1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const int m = s >> 3, j = s & 7, cur = s & 1;
-        if (m > 0) product(m - 1, 3 * j);
-        y[0][j] = dw_eval(0, wt[cur], tp[0][cur]);
-        if (s + 2 < 32) taps_load(0, s + 2, tp[0][cur]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (m > 0) product(m - 1, 3 * j + 1);
-        y[1][j] = dw_eval(1, wt[cur], tp[1][cur]);
-        if (s + 2 < 32) {
-            taps_load(1, s + 2, tp[1][cur]);
-            wts_load(s + 2, wt[cur]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (m > 0) product(m - 1, 3 * j + 2);
-        if (j == 7) {
-            // the products of k-block m-1 are done: its ring slot takes k-block m+1 (or the next block's first)
-            if (m < 3)
-                load_afrag(w, N, m + 1, lane, af[(m + 1) & 1]);
-            else if (N < 4)
-                load_afrag(w, N + 1, 0, lane, af[0]);
-            split3(y[0], fr[0][0], fr[0][1], fr[0][2]);
-            split3(y[1], fr[1][0], fr[1][1], fr[1][2]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 24; ++i) product(3, i);
-
-    if constexpr (N < 4) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (valid[t]) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    zout[row_of(r, half) * G::SOUT + pos[t]] = relu(acc[t][0][r]);
-                    zout[(32 + row_of(r, half)) * G::SOUT + pos[t]] = relu(acc[t][1][r]);
-                }
-            }
-        }
-        store_block_tables(lds, N + 1, tid, next_tables);
-    } else {
-        // global average pool, part 1: sum this wavefront's 60 positions per channel (DPP, no LDS round trips)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = (valid[0] ? relu(acc[0][ct][r]) : 0.f) + (valid[1] ? relu(acc[1][ct][r]) : 0.f);
-                const float sum = half_wave_sum_to_last_lane(v);
-                if (col == 31) poolbuf[wv * CH + ct * 32 + row_of(r, half)] = sum;
-            }
-        }
-    }
-}
 
 template <int MODE>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
@@ -808,9 +633,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     constexpr bool SPLIT = MODE >= 4;
     float a1[SPLIT ? 1 : 50];       // conv1 weights of this wave's output-channel tile (f32 MFMA A operands)
     uintx4 c1f[SPLIT ? 7 : 1][3];   // the same as bf16 pieces (split path)
-    PwOperands<MODE> wa;            // pointwise weights of the running block (whole-block residency)
-    AFrag af[2];                    // ... or a ring of two k-blocks (tile-pair path)
-    constexpr bool PAIR = MODE == 5;
+    PwOperands<MODE> wa;            // pointwise operands of the running block
     if constexpr (SPLIT) {
         const uintx4* src = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(wv & 1) * (7 * 3 * 64) + lane;
 #pragma unroll
@@ -821,7 +644,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const int half = lane >> 5, col = lane & 31, ct = wv & 1;
 #pragma unroll
         for (int s = 0; s < 50; ++s) a1[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
-        load_pointwise<MODE>(w, 1, lane, wa);
+        load_pointwise(w, 1, lane, wa);
     }
     float* featp = lds + OFF_FEAT;
     const float* f = feat + (size_t)clip * (IN_T * IN_F);
@@ -852,11 +675,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     if constexpr (SPLIT) {
         conv1_phase_split(w, lds, tid, c1f);
-        // the conv1 operands are dead: block 1's fly across the barrier
-        if constexpr (PAIR)
-            load_afrag(w, 1, 0, lane, af[0]);
-        else
-            load_pointwise<MODE>(w, 1, lane, wa);
+        load_block_head(w, 1, lane, wa);  // the conv1 operands are dead: block 1's first fly across the barrier
     } else {
         conv1_phase<MFMA>(w, lds, tid, a1);
     }
@@ -869,10 +688,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         a += CH * P0;
     }
 
-    if constexpr (MODE == 5)
-        block_phase_pair<1>(w, lds, tid, af);
-    else
-        block_phase<1, MODE>(w, lds, tid, wa);
+    block_phase<1, MODE>(w, lds, tid, wa);
     stamp();  // 4: block 1 units of wave 0 done
     __syncthreads();
     stamp();  // 5: block 1 barrier
@@ -881,10 +697,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z1 + (i / Blk<1>::POUT) * Blk<1>::SOUT + i % Blk<1>::POUT];
         a += CH * Blk<1>::POUT;
     }
-    if constexpr (MODE == 5)
-        block_phase_pair<2>(w, lds, tid, af);
-    else
-        block_phase<2, MODE>(w, lds, tid, wa);
+    block_phase<2, MODE>(w, lds, tid, wa);
     stamp();  // 6
     __syncthreads();
     stamp();  // 7
@@ -893,10 +706,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z2 + (i / Blk<2>::POUT) * Blk<2>::SOUT + i % Blk<2>::POUT];
         a += CH * Blk<2>::POUT;
     }
-    if constexpr (MODE == 5)
-        block_phase_pair<3>(w, lds, tid, af);
-    else
-        block_phase<3, MODE>(w, lds, tid, wa);
+    block_phase<3, MODE>(w, lds, tid, wa);
     stamp();  // 8
     __syncthreads();
     stamp();  // 9
@@ -905,10 +715,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z3 + (i / Blk<3>::POUT) * Blk<3>::SOUT + i % Blk<3>::POUT];
         a += CH * Blk<3>::POUT;
     }
-    if constexpr (MODE == 5)
-        block_phase_pair<4>(w, lds, tid, af);
-    else
-        block_phase<4, MODE>(w, lds, tid, wa);
+    block_phase<4, MODE>(w, lds, tid, wa);
     stamp();  // 10
     __syncthreads();
     stamp();  // 11
@@ -968,8 +775,7 @@ hipError_t dscnn_init_device() {
     const int lds = LDS_FLOATS * (int)sizeof(float);
     const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -988,7 +794,6 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
         case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 4: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<4>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
-        case 5: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<5>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
     }
