@@ -33,6 +33,9 @@ DSCNN_FLOP_PER_CLIP = 2 * 6_603_008            # SURVEY.md 8a totals: 6 603 008 
 MFCC_FLOP_PER_CLIP = 1.4e6
 PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_BF16_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16 MFMA
+# bf16 MFMA work the split path executes per clip: (42 block units x 48 + 10 conv1 units x 42) MFMAs of 32x32x16
+DSCNN_EXECUTED_BF16_FLOP_PER_CLIP = (42 * 48 + 10 * 42) * 32 * 32 * 16 * 2
 
 
 def shard_bounds(total: int, world: int, rank: int):
@@ -214,6 +217,14 @@ def main():
                 "avg_kernel_ms": dscnn_s * 1e3,
                 "launches": k_n,
                 "flop_per_clip": DSCNN_FLOP_PER_CLIP,
+                "math": "f32 in / f32 out; conv1 and the four 1x1 convolutions run on v_mfma_f32_32x32x16_bf16 as exact "
+                        "three-way bf16 splits (6 MFMAs per f32 product, f32 accumulate); peak/frac are priced against "
+                        "the f32 MFMA peak the dtype names",
+                "bf16_pipe": {
+                    "executed_tflops": DSCNN_EXECUTED_BF16_FLOP_PER_CLIP * B / dscnn_s / 1e12 if dscnn_s > 0 else 0.0,
+                    "peak": PEAK_BF16_TFLOPS,
+                    "frac": DSCNN_EXECUTED_BF16_FLOP_PER_CLIP * B / dscnn_s / 1e12 / PEAK_BF16_TFLOPS if dscnn_s > 0 else 0.0,
+                },
             },
             "hbm_read": {
                 "bytes_per_clip": BYTES_PER_CLIP,
