@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Diagnostics (GPU box): time kws_forward_f32 (DS-CNN alone) for the library selected by KWS_HIP_LIB."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "keyword-spotting_amd"))
+import bench
+from kws import _native
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda", 0)
+ctx = _native.Context(0); ctx.use_torch_stream()
+ctx.load_dscnn(bench.synth_weights(), 12)
+wav = torch.from_numpy(bench.synth_clips(B, 0)).to(dev)
+feat = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
+ctx.mfcc_i16(wav, feat)
+logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
+labels = torch.empty((B,), dtype=torch.int32, device=dev)
+for _ in range(10): ctx.forward_f32(feat, logits, labels)
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(5):
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(40): ctx.forward_f32(feat, logits, labels)
+    t1.record(); torch.cuda.synchronize()
+    best = min(best, t0.elapsed_time(t1) / 40)
+print(f"{os.environ.get('KWS_HIP_LIB', 'default'):50s} dscnn best-of-5 {best:.4f} ms  checksum {float(logits.double().sum()):.6f}")
