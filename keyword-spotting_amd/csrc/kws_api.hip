@@ -72,6 +72,21 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
         }
         seg_count[s] = nchunks - seg_first[s];
     }
+    // which neighbours (chunk + 1, + 2, + 4) share a chunk's segment: drives the in-register segmented sums
+    out.seg.assign(64, 0);
+    bool deep = false;
+    for (int s = 0; s <= nfilt; ++s) {
+        if (seg_count[s] > 8) {
+            err = "a mel segment spans more than 8 chunks of 8 bins";
+            return false;
+        }
+        deep = deep || seg_count[s] > 4;
+        for (int i = 0; i < seg_count[s]; ++i)
+            for (int d = 0; d < 3; ++d)
+                if (i + (1 << d) < seg_count[s]) out.seg[seg_first[s] + i] |= 1 << d;
+    }
+    if (deep)
+        for (int c = 0; c < 64; ++c) out.seg[c] |= 128;
     for (int j = 0; j < nfilt; ++j) {
         if (seg_count[j] > 255 || seg_count[j + 1] > 255) {
             err = "mel segment too long";
@@ -296,7 +311,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
                  o_fw = al(o_rw + sizeof(float) * MEL_CHUNK * 64), o_g = al(o_fw + sizeof(float) * MEL_CHUNK * 64),
                  o_dct = al(o_g + sizeof(uint32_t) * 64), o_slot = al(o_dct + sizeof(float) * dct.size()),
-                 total = al(o_slot + sizeof(int) * (NFFT / 2));
+                 o_seg = al(o_slot + sizeof(int) * (NFFT / 2)), total = al(o_seg + sizeof(int) * 64);
     std::vector<unsigned char> host(total, 0);
     memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
     memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
@@ -305,6 +320,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     memcpy(&host[o_g], mel.gather.data(), sizeof(uint32_t) * 64);
     memcpy(&host[o_dct], dct.data(), sizeof(float) * dct.size());
     memcpy(&host[o_slot], mel.slot.data(), sizeof(int) * (NFFT / 2));
+    memcpy(&host[o_seg], mel.seg.data(), sizeof(int) * 64);
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
@@ -326,6 +342,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->ft.mel_gather = reinterpret_cast<const uint32_t*>(b + o_g);
     c->ft.dct = reinterpret_cast<const float*>(b + o_dct);
     c->ft.mel_slot = reinterpret_cast<const int*>(b + o_slot);
+    c->ft.mel_seg = reinterpret_cast<const int*>(b + o_seg);
 
     FrontendParams& p = c->fp;
     p.n_samples = n_samples;

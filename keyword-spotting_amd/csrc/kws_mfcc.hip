@@ -72,8 +72,8 @@ __device__ __forceinline__ void dft8(cf (&v)[8]) {
 // (LDS-array cycles per tools/lds_model.py: 48 for the exchange, the minimum).
 constexpr int XROW = 72;
 
-// Per-wavefront LDS scratch (bytes): exchange / spectrum / power buffer, chunk partials, log-mel vectors.
-constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_CBUF = 4608, SCR_LBUF = 4608 + 1024, SCR_BYTES = 4608 + 1024 + 512;
+// Per-wavefront LDS scratch (bytes): exchange / spectrum / power buffer, log-mel vectors.
+constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_LBUF = 4608, SCR_BYTES = 4608 + 512;
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 // LDS byte address of a pointer into shared memory (for hand-written ds_* instructions)
@@ -249,7 +249,6 @@ __device__ __forceinline__ float to_unit(float s) { return s; }
 struct PairScratch {
     cf* xbuf;          // 8*XROW complex: exchange buffer / spectrum / power spectrum
     float2* pbuf;      // aliases xbuf
-    float4* cbuf;      // chunk partials
     float* lbuf;       // 2 x 64 centred log-mel values
     const float* dctb; // [numcep][nfp]
     const cf* tw2;     // [8][8]
@@ -261,6 +260,8 @@ struct MelLane {
     float rw[MEL_CHUNK], fw[MEL_CHUNK];  // rising / falling weights of the chunk's bins (0 beyond its length)
     int pslot[4];                        // power-buffer slots of bins lane + 64j
     uint32_t gth;                        // filter `lane`: chunk ranges r0 | nr<<8 | f0<<16 | nf<<24
+    float m1, m2, m4;                    // 1 if chunk lane+1 / +2 / +4 lies in the same inter-edge segment, else 0
+    bool deep;                           // some segment has more than 4 chunks (wave-uniform)
 };
 __device__ __forceinline__ void load_mel_lane(const FrontendTables& t, int lane, MelLane& m) {
 #pragma unroll
@@ -271,6 +272,24 @@ __device__ __forceinline__ void load_mel_lane(const FrontendTables& t, int lane,
 #pragma unroll
     for (int j = 0; j < 4; ++j) m.pslot[j] = t.mel_slot[lane + 64 * j];
     m.gth = t.mel_gather[lane];
+    const int seg = t.mel_seg[lane];  // bit d: chunk lane + 2^d is in the same segment; bit 7: any segment > 4 chunks
+    m.m1 = (seg & 1) ? 1.f : 0.f;
+    m.m2 = (seg & 2) ? 1.f : 0.f;
+    m.m4 = (seg & 4) ? 1.f : 0.f;
+    m.deep = __any((seg & 128) != 0);
+}
+
+// lane c <- lane c+1 across the wavefront (0 shifted in at the top)
+__device__ __forceinline__ float lane_above(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+// Sum of v over the chunks lane, lane+1, ... that belong to the same segment (suffix sum by doubling: after the
+// steps the FIRST chunk of every segment holds the segment total).  Segments of up to 8 chunks.
+__device__ __forceinline__ float segment_suffix_sum(float v, const MelLane& m) {
+    v = fmaf(m.m1, lane_above(v), v);
+    v = fmaf(m.m2, lane_above(lane_above(v)), v);
+    if (m.deep) v = fmaf(m.m4, lane_above(lane_above(lane_above(lane_above(v)))), v);
+    return v;
 }
 
 // One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
@@ -281,7 +300,6 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
                                           float* __restrict__ out_a, float* __restrict__ out_b) {
     cf* xbuf = sc.xbuf;
     float2* pbuf = sc.pbuf;
-    float4* cbuf = sc.cbuf;
     float* lbuf = sc.lbuf;
     const float* dctb = sc.dctb;
     const cf* tw2 = sc.tw2;
@@ -312,25 +330,26 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
             fb_ = fmaf(ml.fw[2 * h + 1], pw.w, fb_);
         }
     }
-    wave_lds_order();
-    cbuf[lane] = make_float4(ra, fa_, rb, fb_);
-    wave_lds_order();
+    // Filter j = rising sum over segment j + falling sum over segment j+1.  The chunks of a segment are adjacent
+    // lanes: a suffix sum by doubling (DPP shifts, no LDS) leaves each segment's total in its first chunk, and lane
+    // j fetches its two totals through the LDS crossbar (ds_bpermute: no memory, no bank conflicts).
+    ra = segment_suffix_sum(ra, ml);
+    fa_ = segment_suffix_sum(fa_, ml);
+    rb = segment_suffix_sum(rb, ml);
+    fb_ = segment_suffix_sum(fb_, ml);
     float la = 0.f, lb = 0.f;
-    if (lane < p.nfilt) {
+    {
         const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
-        float sa = 0.f, sb = 0.f;
-        for (int i = 0; i < nr; ++i) {
-            const float4 qv = cbuf[r0 + i];
-            sa += qv.x;
-            sb += qv.z;
+        const float gra = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * r0, __builtin_bit_cast(int, ra)));
+        const float grb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * r0, __builtin_bit_cast(int, rb)));
+        const float gfa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * q0, __builtin_bit_cast(int, fa_)));
+        const float gfb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * q0, __builtin_bit_cast(int, fb_)));
+        if (lane < p.nfilt) {
+            const float sa = (nr ? gra : 0.f) + (nq ? gfa : 0.f);
+            const float sb = (nr ? grb : 0.f) + (nq ? gfb : 0.f);
+            la = logf(sa == 0.f ? PSF_EPS : sa);
+            lb = logf(sb == 0.f ? PSF_EPS : sb);
         }
-        for (int i = 0; i < nq; ++i) {
-            const float4 qv = cbuf[q0 + i];
-            sa += qv.y;
-            sb += qv.w;
-        }
-        la = logf(sa == 0.f ? PSF_EPS : sa);
-        lb = logf(sb == 0.f ? PSF_EPS : sb);
     }
     // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
     // table-rounding error a -36 log-floor would otherwise amplify.
@@ -436,7 +455,7 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
 
     unsigned char* scr = scr0 + wv * SCR_BYTES;
     const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
-                            reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
+                            reinterpret_cast<float*>(scr + SCR_LBUF),
                             dctb, tw2, nfp};
 
     for (int pr = wv; pr < MFCC_FRAMES_PER_WG / 2; pr += MFCC_WAVES) {
@@ -605,7 +624,7 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
     wave_lds_order();
     if (frame_ok) {
         const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
-                                reinterpret_cast<float4*>(scr + SCR_CBUF), reinterpret_cast<float*>(scr + SCR_LBUF),
+                                reinterpret_cast<float*>(scr + SCR_LBUF),
                                 dctb, tw2, nfp};
         const int row = (int)(fidx % p.num_frames);
         mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
