@@ -3,7 +3,7 @@
 word), on the fused MI355X path and for whole batches of files."""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -37,6 +37,71 @@ class KeywordSpotter:
         wav = torch.from_numpy(np.ascontiguousarray(clips)).to(self.device)
         logits, labels = self.model.infer_pcm16(wav)
         return labels.cpu().numpy(), logits.cpu().numpy()
+
+    def infer_batches(self, batches: Iterable[np.ndarray], max_batch: Optional[int] = None
+                      ) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+        """Host ingest for many batches: every ``int16[B,n]`` host batch is packed into a
+        pinned staging buffer and copied to the GPU on a copy stream while the previous batch runs MFCC + DS-CNN
+        on the compute stream (two staging / device buffer pairs, events between the streams); results come back
+        through pinned buffers.  Yields ``(labels int32[B], logits float32[B,C])`` per batch, in order."""
+        n = self.config.desired_samples
+        copy_stream = torch.cuda.Stream(device=self.device)
+        compute_stream = torch.cuda.Stream(device=self.device)
+        slots = []  # per slot: pinned in, device in, pinned logits, pinned labels, copied event, free event, batch size
+
+        def make_slot(cap: int):
+            return {
+                "cap": cap,
+                "h_in": torch.empty((cap, n), dtype=torch.int16).pin_memory(),
+                "d_in": torch.empty((cap, n), dtype=torch.int16, device=self.device),
+                "h_logits": torch.empty((cap, self.model.num_classes), dtype=torch.float32).pin_memory(),
+                "h_labels": torch.empty((cap,), dtype=torch.int32).pin_memory(),
+                "copied": torch.cuda.Event(),
+                "done": torch.cuda.Event(),
+                "b": 0,
+            }
+
+        def launch(slot, batch):
+            if torch.is_tensor(batch) and batch.dtype == torch.int16 and batch.dim() == 2 and batch.shape[1] == n \
+                    and batch.is_pinned():
+                src, b = batch, batch.shape[0]  # the caller already packed into pinned memory: no host copy
+            else:
+                clips = fix_length(np.atleast_2d(np.asarray(batch, dtype=np.int16)), n)
+                b = clips.shape[0]
+                slot["h_in"][:b].numpy()[...] = clips  # pack into pinned memory
+                src = slot["h_in"][:b]
+            slot["b"] = b
+            with torch.cuda.stream(copy_stream):
+                slot["d_in"][:b].copy_(src, non_blocking=True)
+                slot["copied"].record(copy_stream)
+            with torch.cuda.stream(compute_stream):
+                compute_stream.wait_event(slot["copied"])
+                logits, labels = self.model.infer_pcm16(slot["d_in"][:b])
+                slot["h_logits"][:b].copy_(logits, non_blocking=True)
+                slot["h_labels"][:b].copy_(labels, non_blocking=True)
+                slot["done"].record(compute_stream)
+
+        def collect(slot):
+            slot["done"].synchronize()
+            b = slot["b"]
+            return slot["h_labels"][:b].numpy().copy(), slot["h_logits"][:b].numpy().copy()
+
+        pending = []
+        for batch in batches:
+            b = int(batch.shape[0]) if getattr(batch, "ndim", 1) == 2 else 1
+            cap = max(b, max_batch or 0)
+            if len(slots) < 2:
+                slots.append(make_slot(cap))
+                slot = slots[-1]
+            else:
+                slot = pending.pop(0)  # oldest in flight: hand its results out before reusing its buffers
+                yield collect(slot)
+                if slot["cap"] < b:
+                    slot.update(make_slot(b))
+            launch(slot, batch)
+            pending.append(slot)
+        for slot in pending:
+            yield collect(slot)
 
     def infer_files(self, paths: Sequence[str]) -> List[Tuple[int, str]]:
         clips = []

@@ -488,3 +488,41 @@ def test_streaming_frames_and_labels(native, dev, use_graph):
             assert np.array_equal(labels[clear], o_dscnn.predict(ref).numpy()[clear])
     finally:
         sp.close()
+
+
+def test_host_ingest_double_buffered(dev):
+    """KeywordSpotter.infer_batches (pinned staging, H2D on a copy stream overlapped with compute) returns, batch
+    by batch and in order, exactly what the device-resident fused call returns -- ragged batch sizes, numpy and
+    pre-pinned inputs."""
+    from kws.inference import KeywordSpotter
+    from kws.libs.models import DepthwiseSeparableConv
+
+    torch.manual_seed(3)
+    model = DepthwiseSeparableConv(12)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.normal_(0.0, 0.1)
+    sp = KeywordSpotter(model)
+    batches = [synth_clips(b, seed, "uniform") for seed, b in enumerate([64, 7, 130, 1, 64])]
+    mixed = [b if i % 2 == 0 else torch.from_numpy(b).pin_memory() for i, b in enumerate(batches)]
+    got = list(sp.infer_batches(mixed))
+    assert len(got) == len(batches)
+    for clips, (labels, logits) in zip(batches, got):
+        want_logits, want_labels = model.infer_pcm16(torch.from_numpy(clips).to(dev))
+        assert np.array_equal(labels, want_labels.cpu().numpy())
+        assert np.array_equal(logits, want_logits.cpu().numpy())
+
+
+def test_mfcc_batch_beyond_grid_limit(ctx, dev):
+    """B > 65535 clips: the front end splits the launch (grid.y limit); first, last and boundary clips match the
+    small-batch result bit for bit."""
+    B = 65535 + 70
+    base = torch.from_numpy(synth_clips(256, 11, "uniform")).to(dev)
+    wav = base.repeat((B + 255) // 256, 1)[:B].contiguous()
+    out = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(wav, out)
+    ref = torch.empty((256, 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(base, ref)
+    ctx.sync()
+    for idx in (0, 255, 65534, 65535, 65536, B - 1):
+        assert torch.equal(out[idx], ref[idx % 256]), idx
