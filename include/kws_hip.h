@@ -152,6 +152,18 @@ int kws_stream_state(kws_ctx* ctx, const float** d_feat_ring, int* hops);
 /* Copy the raw feature ring (float32 [n_streams, num_frames, numcep], ring order) into caller memory. */
 int kws_stream_copy_features(kws_ctx* ctx, float* d_out);
 
+/* ---- posteriors (build-defined: the reference's scripts stop at argmax of the logits,
+ * kws/libs/training.py:371) ------------------------------------------------------------------------------ */
+
+/* Softmax over the C logits of every row: float32 [B,C] -> float32 [B,C] (device pointers, C <= 64). */
+int kws_softmax_f32(kws_ctx* ctx, const float* d_logits, int B, int C, float* d_prob);
+
+/* Streaming posterior smoothing for the streams opened with kws_stream_open: softmax of this hop's logits
+ * [n_streams, C], then the mean over the last `window` hops per stream (fewer while the history is shorter),
+ * written to d_smoothed [n_streams, C]; d_label (may be NULL) = argmax of the smoothed vector, first maximum
+ * wins.  The history lives in the context and is reset by kws_stream_open / a change of window or C. */
+int kws_stream_smooth_f32(kws_ctx* ctx, const float* d_logits, int C, int window, float* d_smoothed, int32_t* d_label);
+
 /* ---- augmentation of the training transform (kws/libs/audio_processor.py:151-159,172-233) ---------- */
 
 /* out[b][i] = (silence[b] ? 0 : wav[b][i - shift[b]] / 32768, 0 outside the clip) + bg_vol[b] * bg[bg_off[b] + i]

@@ -156,6 +156,11 @@ struct kws_ctx {
     int* d_hops = nullptr;
     hipGraphExec_t stream_graph = nullptr;
     const void* graph_key[3] = {nullptr, nullptr, nullptr};
+    // posterior smoothing history (kws_stream_smooth_f32): ring [n_streams][window][C], sum [n_streams][C], hop count
+    float* d_post_ring = nullptr;
+    float* d_post_sum = nullptr;
+    int* d_post_count = nullptr;
+    int post_window = 0, post_classes = 0;
 
     // profiling
     bool prof = false;
@@ -582,7 +587,17 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
 }
 
 // ---- streaming ------------------------------------------------------------------------------------
+static void smooth_free(kws_ctx* c) {
+    if (c->d_post_ring) (void)hipFree(c->d_post_ring);
+    if (c->d_post_sum) (void)hipFree(c->d_post_sum);
+    if (c->d_post_count) (void)hipFree(c->d_post_count);
+    c->d_post_ring = c->d_post_sum = nullptr;
+    c->d_post_count = nullptr;
+    c->post_window = c->post_classes = 0;
+}
+
 static void stream_free(kws_ctx* c) {
+    smooth_free(c);
     if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
     if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
     if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
@@ -615,6 +630,44 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, sizeof(int), c->stream));
+    return KWS_OK;
+}
+
+int kws_softmax_f32(kws_ctx* c, const float* d_logits, int B, int C, float* d_prob) {
+    int rc = check_batch(c, d_logits, B, "kws_softmax_f32");
+    if (rc) return rc;
+    if (!d_prob) return fail(c, KWS_EINVAL, "kws_softmax_f32: d_prob is NULL");
+    if (C < 1 || C > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_softmax_f32: C must be in [1, 64]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_softmax(c->stream, d_logits, B, C, d_prob));
+    return KWS_OK;
+}
+
+int kws_stream_smooth_f32(kws_ctx* c, const float* d_logits, int C, int window, float* d_smoothed, int32_t* d_label) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_smooth_f32: call kws_stream_open first");
+    if (!d_logits || !d_smoothed) return fail(c, KWS_EINVAL, "kws_stream_smooth_f32: d_logits / d_smoothed is NULL");
+    if (C < 1 || C > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_stream_smooth_f32: C must be in [1, 64]");
+    if (window < 1 || window > 4096) return fail(c, KWS_EINVAL, "kws_stream_smooth_f32: window must be in [1, 4096]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (window != c->post_window || C != c->post_classes) {  // (re)start the history
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        smooth_free(c);
+        const size_t ring_b = sizeof(float) * (size_t)c->n_streams * window * C, sum_b = sizeof(float) * (size_t)c->n_streams * C;
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_post_ring), ring_b) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&c->d_post_sum), sum_b) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&c->d_post_count), sizeof(int)) != hipSuccess) {
+            smooth_free(c);
+            return fail(c, KWS_ENOMEM, "kws_stream_smooth_f32: device allocation failed");
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_post_ring, 0, ring_b, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_post_sum, 0, sum_b, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_post_count, 0, sizeof(int), c->stream));
+        c->post_window = window;
+        c->post_classes = C;
+    }
+    HIP_TRY(c, launch_smooth_posteriors(c->stream, d_logits, c->n_streams, C, window, c->d_post_ring, c->d_post_sum,
+                                        c->d_post_count, d_smoothed, d_label));
     return KWS_OK;
 }
 

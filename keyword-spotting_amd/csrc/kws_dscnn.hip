@@ -800,4 +800,78 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Posteriors (nothing in the reference: its scripts take argmax of the logits).
+namespace {
+
+// one thread per clip / stream: C <= 64 values, the work is launch latency, not arithmetic
+__device__ __forceinline__ void softmax_row(const float* __restrict__ z, int C, float* __restrict__ p) {
+    float m = z[0];
+    for (int i = 1; i < C; ++i) m = fmaxf(m, z[i]);
+    float sum = 0.f;
+    for (int i = 0; i < C; ++i) {
+        const float e = expf(z[i] - m);
+        p[i] = e;
+        sum += e;
+    }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < C; ++i) p[i] *= inv;
+}
+
+__global__ void kws_softmax_f32_kernel(const float* __restrict__ logits, int B, int C, float* __restrict__ prob) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) softmax_row(logits + (size_t)b * C, C, prob + (size_t)b * C);
+}
+
+// Moving average of the last `window` posterior vectors per stream (ring [S][window][C], running sum [S][C]),
+// then argmax of the smoothed vector (first maximum wins).  count = hops smoothed so far, before this one.
+__global__ void kws_smooth_posteriors_kernel(const float* __restrict__ logits, int S, int C, int window,
+                                             float* __restrict__ ring, float* __restrict__ sum, const int* __restrict__ count_ptr,
+                                             float* __restrict__ smoothed, int32_t* __restrict__ label) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int count = *count_ptr;
+    const int slot = count % window;
+    float p[MAX_CLASSES];
+    softmax_row(logits + (size_t)s * C, C, p);
+    float* r = ring + ((size_t)s * window + slot) * C;
+    float* acc = sum + (size_t)s * C;
+    const float inv = 1.0f / (float)((count + 1 < window) ? count + 1 : window);
+    float best = -1.f;
+    int arg = 0;
+    for (int i = 0; i < C; ++i) {
+        const float old = count >= window ? r[i] : 0.f;
+        const float a = acc[i] + (p[i] - old);
+        acc[i] = a;
+        r[i] = p[i];
+        const float v = a * inv;
+        smoothed[(size_t)s * C + i] = v;
+        if (v > best) {
+            best = v;
+            arg = i;
+        }
+    }
+    if (label) label[s] = arg;
+}
+
+__global__ void kws_tick_kernel(int* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1;
+}
+
+}  // namespace
+
+hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob) {
+    hipLaunchKernelGGL(kws_softmax_f32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, d_logits, B, C, d_prob);
+    return hipGetLastError();
+}
+
+hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
+                                    float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label) {
+    hipLaunchKernelGGL(kws_smooth_posteriors_kernel, dim3((S + 63) / 64), dim3(64), 0, s, d_logits, S, C, window, d_ring, d_sum,
+                       d_count, d_smoothed, d_label);
+    hipLaunchKernelGGL(kws_tick_kernel, dim3(1), dim3(64), 0, s, d_count);
+    return hipGetLastError();
+}
+
 }  // namespace kws

@@ -113,6 +113,10 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
                         const int* d_ring_hops = nullptr);
 
+hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
+hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
+                                    float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label);
+
 extern const char* const kKernelNames[KWS_K_COUNT];
 
 }  // namespace kws

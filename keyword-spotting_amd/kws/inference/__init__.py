@@ -139,7 +139,7 @@ class StreamingSpotter:
     """
 
     def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
-                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False):
+                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False, smooth_window: int = 0):
         from kws import _native
 
         self.config = config or AudioConfig()
@@ -155,16 +155,25 @@ class StreamingSpotter:
         self._hop_buf = torch.zeros((self.n_streams, self.hop), dtype=torch.int16, device=self.device)
         self._logits = torch.zeros((self.n_streams, self.model.num_classes), dtype=torch.float32, device=self.device)
         self._labels = torch.zeros((self.n_streams,), dtype=torch.int32, device=self.device)
+        # posterior smoothing: softmax of every hop's logits averaged over the last
+        # `smooth_window` hops per stream on the device (kws_stream_smooth_f32); 0 = raw logits / argmax
+        self.smooth_window = int(smooth_window)
+        self._smoothed = torch.zeros_like(self._logits) if self.smooth_window > 0 else None
         torch.cuda.synchronize(self.device)
 
     def push(self, samples) -> Tuple[np.ndarray, np.ndarray]:
-        """``int16[n_streams, hop]`` (host array or device tensor) -> (labels int32[S], logits float32[S,C])."""
+        """``int16[n_streams, hop]`` (host array or device tensor) -> (labels int32[S], logits float32[S,C]);
+        with ``smooth_window`` > 0 the second array holds the smoothed posteriors and the labels are their argmax."""
         x = samples if isinstance(samples, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(samples, dtype=np.int16))
         if tuple(x.shape) != (self.n_streams, self.hop) or x.dtype != torch.int16:
             raise ModelError(f"push expects int16 [{self.n_streams}, {self.hop}]")
         self._hop_buf.copy_(x, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()  # the context runs on its own stream
         self._ctx.stream_push_i16(self._hop_buf, self._logits, self._labels, use_graph=self.use_graph)
+        if self.smooth_window > 0:
+            self._ctx.stream_smooth_f32(self._logits, self.smooth_window, self._smoothed, self._labels)
+            self._ctx.sync()
+            return self._labels.cpu().numpy(), self._smoothed.cpu().numpy()
         self._ctx.sync()
         return self._labels.cpu().numpy(), self._logits.cpu().numpy()
 

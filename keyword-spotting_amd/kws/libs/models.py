@@ -6,7 +6,7 @@ Drop-in for the reference's ``kws/libs/models.py``: ``KeywordSpottingModel`` (``
 names, shapes and initialisation, so reference checkpoints (bare ``state_dict`` or the trainer's
 ``{"model_state_dict": ...}``) load unchanged.  The modules only *hold* parameters; the arithmetic of
 ``forward`` is ``kws_forward_f32`` (include/kws_hip.h): LDS-resident activations, depthwise 3x3 on the
-VALU, pointwise 1x1 and conv1 on the f32 matrix cores.  Inference only -- no autograd graph is built.
+VALU, pointwise 1x1 and conv1 on the matrix cores.  Inference only -- no autograd graph is built.
 """
 from __future__ import annotations
 
@@ -141,3 +141,59 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
         labels = torch.empty((wav.shape[0],), dtype=torch.int32, device=wav.device)
         ctx.infer_i16(wav, logits, labels)
         return logits, labels
+
+
+class DepthwiseSeparableConvBN(KeywordSpottingModel):
+    """Build-defined model-zoo member (the reference has no BatchNorm): the same DS-CNN
+    with an inference-mode BatchNorm2d after conv1, after every depthwise and after every pointwise convolution
+    (conv -> BN -> ReLU where the plain model has conv -> ReLU).  ``fold()`` folds every BatchNorm into the
+    convolution before it -- w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta -- which
+    yields an ordinary ``DepthwiseSeparableConv`` whose forward is the fused kernel.  The relu(bias) ring of the
+    padded 1x1 convolutions stays exact: a BatchNorm acts per channel, ring included.  Inference only."""
+
+    def __init__(self, num_classes: int = 12, eps: float = 1e-5):
+        super().__init__(num_classes)
+        self.plain = DepthwiseSeparableConv(num_classes)
+        self.bn_conv1 = nn.BatchNorm2d(64, eps=eps)
+        self.bn_dw = nn.ModuleList([nn.BatchNorm2d(64, eps=eps) for _ in range(4)])
+        self.bn_pw = nn.ModuleList([nn.BatchNorm2d(64, eps=eps) for _ in range(4)])
+        object.__setattr__(self, "_folded", None)  # kept out of nn.Module's child registry: not a parameter holder
+        self._folded_key = None
+
+    @staticmethod
+    def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach()
+        w = conv.weight.detach() * scale.reshape(-1, 1, 1, 1)
+        b = (conv.bias.detach() - bn.running_mean) * scale + bn.bias.detach()
+        return w, b
+
+    def fold(self) -> DepthwiseSeparableConv:
+        """The equivalent plain model (cached until a parameter or running statistic changes)."""
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if self._folded is not None and key == self._folded_key:
+            return self._folded
+        out = DepthwiseSeparableConv(self.num_classes)
+        with torch.no_grad():
+            w, b = self._fold(self.plain.conv1, self.bn_conv1)
+            out.conv1.weight.copy_(w)
+            out.conv1.bias.copy_(b)
+            for i in range(4):
+                src = getattr(self.plain, f"dsconv{i + 1}")
+                dst = getattr(out, f"dsconv{i + 1}")
+                w, b = self._fold(src.depthwise, self.bn_dw[i])
+                dst.depthwise.weight.copy_(w)
+                dst.depthwise.bias.copy_(b)
+                w, b = self._fold(src.pointwise, self.bn_pw[i])
+                dst.pointwise.weight.copy_(w)
+                dst.pointwise.bias.copy_(b)
+            out.fc.weight.copy_(self.plain.fc.weight)
+            out.fc.bias.copy_(self.plain.fc.bias)
+        object.__setattr__(self, "_folded", out)
+        self._folded_key = key
+        return out
+
+    def forward(self, x: torch.Tensor, return_labels: bool = False):
+        return self.fold().forward(x, return_labels)
+
+    def infer_pcm16(self, wav: torch.Tensor):
+        return self.fold().infer_pcm16(wav)

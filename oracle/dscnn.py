@@ -85,3 +85,21 @@ def flatten_state(state: dict) -> np.ndarray:
     """The 20 tensors in ``state_dict`` order as one float32 vector (the blob
     layout ``kws_load_dscnn`` takes)."""
     return np.concatenate([np.asarray(state[k], dtype=np.float32).reshape(-1) for k in STATE_KEYS if k in state])
+
+
+def forward_bn(state: dict, bn: dict, x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """CPU definition of the build's BatchNorm variant (not in the reference): the DS-CNN
+    with an inference-mode BatchNorm after conv1, every depthwise and every pointwise convolution, applied
+    UNFOLDED.  bn[name] = (gamma, beta, running_mean, running_var) for name in conv1, dw1..4, pw1..4."""
+    import torch.nn.functional as F
+
+    def norm(y, name):
+        g, b, m, v = bn[name]
+        return F.batch_norm(y, m, v, g, b, training=False, eps=eps)
+
+    y = F.relu(norm(F.conv2d(x, state["conv1.weight"], state["conv1.bias"], stride=2, padding=2), "conv1"))
+    for i in range(1, 5):
+        y = norm(F.conv2d(y, state[f"dsconv{i}.depthwise.weight"], state[f"dsconv{i}.depthwise.bias"], padding=1, groups=64), f"dw{i}")
+        y = F.relu(norm(F.conv2d(y, state[f"dsconv{i}.pointwise.weight"], state[f"dsconv{i}.pointwise.bias"], padding=1), f"pw{i}"))
+    y = F.adaptive_avg_pool2d(y, (1, 1)).view(y.size(0), -1)
+    return F.linear(y, state["fc.weight"], state["fc.bias"])

@@ -526,3 +526,81 @@ def test_mfcc_batch_beyond_grid_limit(ctx, dev):
     ctx.sync()
     for idx in (0, 255, 65534, 65535, 65536, B - 1):
         assert torch.equal(out[idx], ref[idx % 256]), idx
+
+
+# ------------------------------------------------------------------------------ model zoo / posteriors (section 8 f-4)
+def test_batchnorm_variant_folds_into_the_fused_kernel(dev):
+    """DepthwiseSeparableConvBN (build-defined: inference BatchNorm after every convolution) equals its own
+    unfolded torch-CPU definition (oracle.dscnn.forward_bn) within the logit tolerance, identical argmax."""
+    from kws.libs.models import DepthwiseSeparableConvBN
+
+    torch.manual_seed(5)
+    m = DepthwiseSeparableConvBN(12)
+    with torch.no_grad():
+        for prm in m.plain.parameters():
+            prm.normal_(0.0, 0.1)
+        for bn in [m.bn_conv1, *m.bn_dw, *m.bn_pw]:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0.0, 0.2)
+            bn.running_mean.normal_(0.0, 0.3)
+            bn.running_var.uniform_(0.3, 2.0)
+    x = torch.randn(33, 1, 99, 10)
+    state = {k: v.detach().clone() for k, v in m.plain.state_dict().items()}
+    names = ["conv1"] + [f"dw{i}" for i in range(1, 5)] + [f"pw{i}" for i in range(1, 5)]
+    mods = [m.bn_conv1] + list(m.bn_dw) + list(m.bn_pw)
+    bn = {n: (b.weight.detach(), b.bias.detach(), b.running_mean.clone(), b.running_var.clone()) for n, b in zip(names, mods)}
+    want = o_dscnn.forward_bn(state, bn, x)
+    logits, labels = m.forward(x.to(dev), return_labels=True)
+    err = (logits.cpu() - want).abs().max().item()
+    assert err <= TOL, err
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()
+    assert np.array_equal(labels.cpu().numpy()[clear], want.argmax(dim=1).numpy()[clear])
+    # the folded model is cached until a statistic changes
+    assert m.fold() is m.fold()
+    with torch.no_grad():
+        m.bn_pw[3].bias.add_(1.0)
+    assert m.fold() is not None and m._folded_key is not None
+    logits2 = m.forward(x.to(dev))
+    assert (logits2.cpu() - logits.cpu()).abs().max().item() > 1e-3
+
+
+def test_softmax_and_streaming_posterior_smoothing(native, dev):
+    from kws.inference import StreamingSpotter
+    from kws.libs.models import DepthwiseSeparableConv
+
+    # softmax entry against numpy
+    c = native.Context(0)
+    c.use_torch_stream()
+    z = torch.randn(257, 12, device=dev) * 5
+    p = torch.empty_like(z)
+    c.softmax_f32(z, p)
+    c.sync()
+    zn = z.cpu().numpy().astype(np.float64)
+    e = np.exp(zn - zn.max(axis=1, keepdims=True))
+    assert np.abs(p.cpu().numpy() - e / e.sum(axis=1, keepdims=True)).max() <= 1e-6
+    c.close()
+
+    # streaming: smoothed posteriors = mean of the softmax of the last W hops' logits (fewer at the start)
+    torch.manual_seed(9)
+    model = DepthwiseSeparableConv(12)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.normal_(0.0, 0.1)
+    S, W, hops = 5, 4, 11
+    raw = StreamingSpotter(S, model)
+    smo = StreamingSpotter(S, model, smooth_window=W)
+    rng = np.random.default_rng(2)
+    hist = []
+    for h in range(hops):
+        hop = rng.integers(-20000, 20000, size=(S, raw.hop), dtype=np.int16)
+        _, logits = raw.push(hop)
+        labels, post = smo.push(hop)
+        zn = logits.astype(np.float64)
+        e = np.exp(zn - zn.max(axis=1, keepdims=True))
+        hist.append(e / e.sum(axis=1, keepdims=True))
+        want = np.mean(hist[-W:], axis=0)
+        assert np.abs(post - want).max() <= 2e-6, h
+        assert np.array_equal(labels, want.argmax(axis=1))
+    raw.close()
+    smo.close()
