@@ -604,12 +604,16 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 }
 
 
-template <int MODE>
+// DIAG = false: the product instantiation -- no activation dump, no stamps (their pointers and loops cost
+// registers and 5 KB of code even when unused).
+template <int MODE, bool DIAG = true>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
-                                                           float* __restrict__ act,
-                                                           unsigned long long* __restrict__ stamps,
+                                                           float* __restrict__ act_arg,
+                                                           unsigned long long* __restrict__ stamps_arg,
                                                            const int* __restrict__ ring_hops) {
+    float* const act = DIAG ? act_arg : nullptr;
+    unsigned long long* const stamps = DIAG ? stamps_arg : nullptr;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool MFMA = MODE != 0;
     const int tid = threadIdx.x;
@@ -775,7 +779,8 @@ hipError_t dscnn_init_device() {
     const int lds = LDS_FLOATS * (int)sizeof(float);
     const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -793,7 +798,12 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
         case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
-        case 4: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<4>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 4:
+            if (d_act || d_stamps)
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops);
+            else
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops);
+            break;
         case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
         default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
     }
