@@ -17,10 +17,10 @@ constexpr int NFFT = 512;
 constexpr int NBINS = NFFT / 2 + 1;       // 257
 constexpr int MEL_CHUNK = 8;              // bins per lane in the sparse mel stage
 #ifndef KWS_MFCC_WAVES
-#define KWS_MFCC_WAVES 3
+#define KWS_MFCC_WAVES 4
 #endif
 #ifndef KWS_MFCC_PAIRS_PER_WAVE
-#define KWS_MFCC_PAIRS_PER_WAVE 4
+#define KWS_MFCC_PAIRS_PER_WAVE 3
 #endif
 constexpr int MFCC_WAVES = KWS_MFCC_WAVES;             // wavefronts per workgroup
 constexpr int MFCC_THREADS = MFCC_WAVES * 64;

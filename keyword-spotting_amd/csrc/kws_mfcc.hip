@@ -2,8 +2,8 @@
 // (reference call site kws/libs/audio_processor.py:270-278; stages a1-a8 of SURVEY.md section 8).
 //
 // Work decomposition
-//   grid = (ceil(num_frames / 24), B); a workgroup is MFCC_WAVES (3) wavefronts and owns 24 frames
-//   (12 frame pairs, four per wavefront; shape chosen by A/B timing on MI355X).  Together
+//   grid = (ceil(num_frames / 24), B); a workgroup is MFCC_WAVES (4) wavefronts and owns 24 frames
+//   (12 frame pairs, three per wavefront; shape chosen by A/B timing on MI355X).  Together
 //   the waves stage the PCM span of those frames (4080 samples for 400/160) from HBM with 16-byte loads,
 //   convert to float32, apply pre-emphasis once
 //   and keep the span in LDS, next to the tables every wave needs (DCT x lifter, sparse-mel weights,
@@ -485,12 +485,14 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     }
 }
 
-__global__ __launch_bounds__(MFCC_THREADS) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
+// amdgpu_waves_per_eu(4, 4): 128 registers, so that the four 4-wave workgroups the LDS admits per CU (16
+// wavefronts, 4 per SIMD) all become resident; the kernel is latency-bound on LDS round trips.
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
                                                                     float* __restrict__ out) {
     mfcc_body<int16_t>(p, t, wav, out);
 }
-__global__ __launch_bounds__(MFCC_THREADS) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
                                                                     const float* __restrict__ wav,
                                                                     float* __restrict__ out) {
     mfcc_body<float>(p, t, wav, out);
