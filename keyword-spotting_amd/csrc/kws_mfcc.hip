@@ -409,7 +409,10 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     // ---- stage PCM span -> float32, pre-emphasised, in LDS; shared tables -------------------------
     const int s0 = f0 * p.frame_step;
     const float c = p.preemph;
-    for (int g = tid; g * 8 < p.chunk_samples; g += MFCC_THREADS) {
+    // the clip's last workgroup owns fewer frames (3 of 24 for 99 frames): it stages only the span they cover
+    const int my_frames = min(MFCC_FRAMES_PER_WG, p.num_frames - f0);
+    const int my_samples = (my_frames - 1) * p.frame_step + p.frame_len;
+    for (int g = tid; g * 8 < my_samples; g += MFCC_THREADS) {
         const int n = s0 + g * 8;
         float y[8];
         if (sizeof(T) == 2 && p.vec_ok && n + 8 <= p.n_samples) {
