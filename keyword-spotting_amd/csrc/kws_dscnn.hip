@@ -62,6 +62,12 @@ static_assert(NW * 64 <= 768, "pool scratch must fit one depthwise buffer");
 static_assert(OFF_FEAT + FEAT_H * FEAT_W <= OFF_Z2, "feature pad overlaps Z2");
 static_assert(CH * 12 <= 2 * NT, "table staging assumes at most two elements per thread");
 
+// Activation planes in LDS are stored as channel PAIRS interleaved per position: element (c, p) of a map whose
+// planes hold S floats lives at (c >> 1) * 2S + 2p + (c & 1).  One ds_read_b64 then fetches a column's value for
+// two consecutive channels (the split path walks channels two at a time) and the epilogue stores two output
+// channels with one ds_write_b64: half the tap reads and stores, at twice the bytes per LDS cycle.
+__device__ __forceinline__ constexpr int pidx(int c, int p, int S) { return (c >> 1) * 2 * S + 2 * p + (c & 1); }
+
 // Geometry of block N (1..4): output plane H x W (all of it is the next block's interior).
 template <int N>
 struct Blk {
@@ -244,7 +250,7 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = ct * 32 + row_of(r, half);
-                    z0[co * (P0 + 2) + pos] = relu(acc[r] + w.c1_b[co]);
+                    z0[pidx(co, pos, P0 + 2)] = relu(acc[r] + w.c1_b[co]);
                 }
             }
         }
@@ -256,12 +262,12 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
             for (int kh = 0; kh < C1_K; ++kh)
                 for (int kw = 0; kw < C1_K; ++kw)
                     acc = fmaf(w.c1_w[(kh * C1_K + kw) * CH + co], featp[(2 * oh + kh) * FEAT_W + 2 * ow + kw], acc);
-            z0[co * (P0 + 2) + pos] = relu(acc);
+            z0[pidx(co, pos, P0 + 2)] = relu(acc);
         }
     }
     if (tid < CH) {  // extra slots of the conv1 planes: no ring in block 1, slot P+1 is the zero pad
-        z0[tid * (P0 + 2) + P0] = 0.f;
-        z0[tid * (P0 + 2) + P0 + 1] = 0.f;
+        z0[pidx(tid, P0, P0 + 2)] = 0.f;
+        z0[pidx(tid, P0 + 1, P0 + 2)] = 0.f;
     }
 }
 
@@ -324,15 +330,16 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
         acc += acc2;
         if (pos < P0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
                 const int co = ct * 32 + row_of(r, half);
-                z0[co * (P0 + 2) + pos] = relu(acc[r] + w.c1_b[co]);
+                *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) =
+                    make_float2(relu(acc[r] + w.c1_b[co]), relu(acc[r + 1] + w.c1_b[co + 1]));
             }
         }
     }
     if (tid < CH) {  // extra slots of the conv1 planes: no ring in block 1, slot P+1 is the zero pad
-        z0[tid * (P0 + 2) + P0] = 0.f;
-        z0[tid * (P0 + 2) + P0 + 1] = 0.f;
+        z0[pidx(tid, P0, P0 + 2)] = 0.f;
+        z0[pidx(tid, P0 + 1, P0 + 2)] = 0.f;
     }
 }
 
@@ -363,8 +370,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (N < 4) {
         fetch_block_tables(w, N + 1, tid, next_tables);
         if (tid < CH) {
-            zout[tid * G::SOUT + G::POUT] = relu(pwb[tid]);
-            zout[tid * G::SOUT + G::POUT + 1] = 0.f;
+            zout[pidx(tid, G::POUT, G::SOUT)] = relu(pwb[tid]);
+            zout[pidx(tid, G::POUT + 1, G::SOUT)] = 0.f;
         }
     } else if (!MFMA) {
         poolbuf[wv * CH + lane] = 0.f;  // the VALU path accumulates into its wave's scratch row
@@ -397,7 +404,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
             const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
             const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
-            tlo[dh + 1] = G::OFF_IN + a + half * (SPLIT ? 8 : 1) * G::SIN;
+            tlo[dh + 1] = G::OFF_IN + pidx(half * (SPLIT ? 8 : 1), a, G::SIN);
             thi[dh + 1] = tlo[dh + 1] + 32 * G::SIN;
             asm volatile("" : "+v"(tlo[dh + 1]));
             asm volatile("" : "+v"(thi[dh + 1]));
@@ -414,10 +421,32 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             tp.q1 = dwt4[cs * 3 + 1];
             tp.q2 = dwt4[cs * 3 + 2];
             const int* ta = cs < 32 ? tlo : thi;
-            const int o = (cs & 31) * G::SIN;
+            // offset of channel (base channel + cs&31) relative to the base: the f32 / VALU walk (base parity =
+            // half, step 2) stays on one member of a pair; the split walk starts on an even channel
+            const int o = SPLIT ? pidx(cs & 31, 0, G::SIN) : (cs & 31) * G::SIN;
             tp.up = lds[ta[0] + o];
             tp.mid = lds[ta[1] + o];
             tp.dn = lds[ta[2] + o];
+        };
+        // split path: the own-column inputs of channels (cs, cs+1), cs even, in three 8-byte reads
+        struct TapPair {
+            float2 up, mid, dn;
+        };
+        auto tap_pair_load = [&](int sp, TapPair& tp) {  // sp: pair of steps (2sp, 2sp+1)
+            const int cs = cs_of(2 * sp);
+            const int* ta = cs < 32 ? tlo : thi;
+            const int o = (cs & 31) * G::SIN;
+            if constexpr (!NO_STENCIL) {
+                tp.up = *reinterpret_cast<const float2*>(lds + ta[0] + o);
+                tp.dn = *reinterpret_cast<const float2*>(lds + ta[2] + o);
+            }
+            tp.mid = *reinterpret_cast<const float2*>(lds + ta[1] + o);
+        };
+        auto wts_load = [&](int s, Taps& tp) {
+            const int cs = cs_of(s);
+            tp.q0 = dwt4[cs * 3 + 0];
+            tp.q1 = dwt4[cs * 3 + 1];
+            tp.q2 = dwt4[cs * 3 + 2];
         };
         // depthwise 3x3 (+bias) of this step's channel at this lane's column -> one MFMA B operand element
         auto dw_eval = [&](const Taps& tp) -> float {
@@ -435,8 +464,18 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             }
             // software pipeline, two steps deep: reads of step s+2 are issued before step s is evaluated
             Taps ta0, ta1;
-            dw_load(0, ta0);
-            dw_load(1, ta1);
+            TapPair tq0, tq1;  // split path: inputs of step pairs, two pairs in flight
+            if constexpr (SPLIT) {
+                if constexpr (!NO_STENCIL) {
+                    wts_load(0, ta0);
+                    wts_load(1, ta1);
+                }
+                tap_pair_load(0, tq0);
+                tap_pair_load(1, tq1);
+            } else {
+                dw_load(0, ta0);
+                dw_load(1, ta1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SPLIT) {
                 // eight depthwise outputs fill one k-block of 16 input channels (8 per half-wave); they are split
@@ -460,16 +499,19 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 for (int s = 0; s < 32; ++s) {
                     const int m = s >> 3, j = s & 7;
                     Taps& tp = (s & 1) ? ta1 : ta0;
+                    TapPair& tq = (s & 2) ? tq1 : tq0;  // step pair s >> 1
                     const bool feed = m > 0 && j < 6;
                     if (feed) product(0, m - 1, j);
+                    tp.up = (s & 1) ? tq.up.y : tq.up.x;
+                    tp.mid = (s & 1) ? tq.mid.y : tq.mid.x;
+                    tp.dn = (s & 1) ? tq.dn.y : tq.dn.x;
                     y[j] = NO_STENCIL ? tp.mid : dw_eval(tp);
                     __builtin_amdgcn_sched_barrier(0);
                     if (feed) product(1, m - 1, j);
-                    if constexpr (NO_STENCIL) {
-                        if (s + 2 < 32) tp.mid = lds[(cs_of(s + 2) < 32 ? tlo : thi)[1] + (cs_of(s + 2) & 31) * G::SIN];
-                    } else {
-                        if (s + 2 < 32) dw_load(s + 2, tp);
+                    if constexpr (!NO_STENCIL) {
+                        if (s + 2 < 32) wts_load(s + 2, tp);
                     }
+                    if ((s & 1) && s + 3 < 32) tap_pair_load((s >> 1) + 2, tq);  // both steps of the pair are done
                     __builtin_amdgcn_sched_barrier(0);
                     if (j == 6) {
                         // the products of k-block m-1 are done: its ring slot takes k-block m+1, or k-block 0 of
@@ -529,9 +571,11 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 if constexpr (N < 4) {
                     if (valid) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            zout[row_of(r, half) * G::SOUT + pos] = relu(acc0[r]);
-                            zout[(32 + row_of(r, half)) * G::SOUT + pos] = relu(acc1[r]);
+                        for (int r = 0; r < 16; r += 2) {  // rows r, r+1 are adjacent output channels: one 8-byte store
+                            *reinterpret_cast<float2*>(zout + pidx(row_of(r, half), pos, G::SOUT)) =
+                                make_float2(relu(acc0[r]), relu(acc0[r + 1]));
+                            *reinterpret_cast<float2*>(zout + pidx(32 + row_of(r, half), pos, G::SOUT)) =
+                                make_float2(relu(acc1[r]), relu(acc1[r + 1]));
                         }
                     }
                 } else {
@@ -572,7 +616,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 for (int s = 0; s < 32; ++s) part = fmaf(pw_w[(2 * s + half) * CH + co], y[s], part);
                 const float tot = relu(part + __shfl_xor(part, 32, 64) + pwb[co]);
                 if constexpr (N < 4) {
-                    if (valid && half == 0) zout[co * G::SOUT + pos] = tot;
+                    if (valid && half == 0) zout[pidx(co, pos, G::SOUT)] = tot;
                 } else {
                     // pool: sum this tile's positions and accumulate into the wave's own scratch row
                     float sum = (valid && half == 0) ? tot : 0.f;
@@ -688,7 +732,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 3: conv1 barrier
     float* a = act ? act + (size_t)clip * KWS_ACT_FLOATS_PER_CLIP : nullptr;
     if (a) {
-        for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + (i / P0) * (P0 + 2) + i % P0];
+        for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)];
         a += CH * P0;
     }
 
@@ -698,7 +742,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 5: block 1 barrier
     if (a) {
         for (int i = tid; i < CH * Blk<1>::POUT; i += NT)
-            a[i] = lds[OFF_Z1 + (i / Blk<1>::POUT) * Blk<1>::SOUT + i % Blk<1>::POUT];
+            a[i] = lds[OFF_Z1 + pidx(i / Blk<1>::POUT, i % Blk<1>::POUT, Blk<1>::SOUT)];
         a += CH * Blk<1>::POUT;
     }
     block_phase<2, MODE>(w, lds, tid, wa);
@@ -707,7 +751,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 7
     if (a) {
         for (int i = tid; i < CH * Blk<2>::POUT; i += NT)
-            a[i] = lds[OFF_Z2 + (i / Blk<2>::POUT) * Blk<2>::SOUT + i % Blk<2>::POUT];
+            a[i] = lds[OFF_Z2 + pidx(i / Blk<2>::POUT, i % Blk<2>::POUT, Blk<2>::SOUT)];
         a += CH * Blk<2>::POUT;
     }
     block_phase<3, MODE>(w, lds, tid, wa);
@@ -716,7 +760,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 9
     if (a) {
         for (int i = tid; i < CH * Blk<3>::POUT; i += NT)
-            a[i] = lds[OFF_Z3 + (i / Blk<3>::POUT) * Blk<3>::SOUT + i % Blk<3>::POUT];
+            a[i] = lds[OFF_Z3 + pidx(i / Blk<3>::POUT, i % Blk<3>::POUT, Blk<3>::SOUT)];
         a += CH * Blk<3>::POUT;
     }
     block_phase<4, MODE>(w, lds, tid, wa);
