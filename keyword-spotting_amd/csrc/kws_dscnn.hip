@@ -1,6 +1,6 @@
-// DS-CNN forward for gfx950 (MI355X): one 512-thread workgroup per clip, every activation resident in
-// the CU's 160 KiB LDS, pointwise 1x1 convolutions and conv1 on the exact-f32 matrix cores
-// (v_mfma_f32_32x32x2_f32), depthwise 3x3 on the VALU straight into the MFMA B-operand registers.
+// DS-CNN forward for gfx950 (MI355X): one 512-thread workgroup per clip, every activation resident in the
+// CU's 160 KiB LDS; conv1 and the pointwise 1x1 convolutions on the matrix cores, depthwise 3x3 on the VALU
+// straight into the MFMA B-operand registers.
 //
 // Replaces DepthwiseSeparableConv.forward (reference kws/libs/models.py:160-183; rows a9-a15 of
 // SURVEY.md section 8) for the [1,99,10] MFCC map:
@@ -8,27 +8,35 @@
 //   4 x { depthwise 3x3 pad 1 ; pointwise 1x1 *padding=1* ; ReLU }  -> 64 x (49x5, 51x7, 53x9, 55x11)
 //   global average pool, Linear(64 -> C), argmax (first maximum wins)
 //
+// Two arithmetic routes for the GEMMs, same f32 results (include/kws_hip.h, kws_set_pointwise_math):
+//   split-bf16 (product): every f32 operand = hi + mid + lo, three bf16 pieces that reproduce it exactly; the six
+//     piece products of combined order <= 2 on v_mfma_f32_32x32x16_bf16 (f32 accumulate) give the f32 product to
+//     2^-24.  16x the f32 MFMA rate, and the bf16 pipe runs beside the VALU (the f32 MFMA shares its datapath).
+//   f32: v_mfma_f32_32x32x2_f32.
+// A third variant runs the GEMMs on the VALU: an independent check of the operand mappings (tests only).
+//
 // The relu(bias) ring.  The reference's 1x1 convolution with padding=1 surrounds each block's output
 // with a ring equal to relu(bias) (models.py:104-106).  The ring is never stored: each channel plane in
 // LDS holds only the "interior" H x W values followed by two extra slots, [P] = relu(bias[c]) and
 // [P+1] = 0.  A depthwise tap that falls on the ring reads slot P, one that falls outside the padded
 // map reads slot P+1, so a stencil tap is an unconditional LDS read at a per-lane precomputed address.
 //
-// MFMA mapping (32x32x2, D[i][j] += A[i][k] * B[k][j]): i = output channel, j = position, k = input
-// channel.  Lane l supplies A[i = l&31][k = l>>5] (weights, in registers for the whole block) and
-// B[k = l>>5][j = l&31]: lane l computes the depthwise output of column j for input channels
-// 2s + (l>>5), s = 0..31, and feeds it to the matrix core without touching LDS.
+// MFMA mapping, split path (32x32x16, D[i][j] += A[i][k] * B[k][j]): i = output channel, j = position, k = input
+// channel.  Lane l supplies B[k = 8(l>>5) + e][j = l&31], e = 0..7: it computes the depthwise output of column j
+// for input channels 16m + 8(l>>5) + e itself (m = k-block), splits the eight values into bf16 pieces and feeds
+// them to the matrix core without touching LDS; A = pre-split weights from a two-k-block register ring.
+// (f32 path, 32x32x2: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31], channels 2s + (l>>5).)
 // D: column = lane&31 (position), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel).
 //
 // Stencil with 3 LDS reads instead of 9.  The 32 MFMA columns of a tile are 30 consecutive output
 // positions plus one halo column on each side.  A lane reads only its own column (rows h-1, h, h+1);
 // because the depthwise weights are the same in all 32 lanes of a half-wave, each lane forms the two
-// 3-tap column sums its right and left neighbours need and hands them over with one DPP wave shift
-// each.  A neighbour that belongs to another row (x == 0 or x == W-1) is outside the zero-padded map,
-// so its contribution is multiplied by a per-lane 0/1 mask.  The reads of step s+2 are in flight while
-// step s is evaluated and the matrix core works through the two MFMAs of the previous step.
+// 3-tap column sums its right and left neighbours need, and the neighbours' sums arrive through one fused DPP
+// multiply-add each.  A neighbour that belongs to another row (x == 0 or x == W-1) is outside the zero-padded
+// map, so its contribution is multiplied by a per-lane 0/1 mask.  The reads of step s+2 are in flight while
+// step s is evaluated and the matrix core works through the MFMAs of the previous k-block.
 //
-// LDS map (floats): planes are channel-major [64][P+2]
+// LDS map (floats): planes hold P+2 floats and are interleaved in channel pairs (see pidx)
 //   Z3 (block3 out, 51x7)  @ 0      .. 22976     Z2 (block2 out, 49x5) @ 22976 .. 38784
 //   Z1 (block1 out, 47x3)  @ 0      .. 9152      Z0 (conv1 out, 47x3)  @ 9152  .. 18304
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
@@ -287,9 +295,13 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
         const float* base = featp + (2 * oh + 5 * half) * FEAT_W + 2 * ow;
         floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;  // two chains keep the matrix pipe fed
         float y[2][8];
-        auto gather = [&](int kb, float (&dst)[8]) {
+        auto gather = [&](int kb, float (&dst)[8]) {  // offsets f, f+1 (f even) are neighbours in one row: 8-byte reads
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j] = base[((8 * kb + j) / 10) * FEAT_W + (8 * kb + j) % 10];
+            for (int j = 0; j < 8; j += 2) {
+                const float2 v = *reinterpret_cast<const float2*>(base + ((8 * kb + j) / 10) * FEAT_W + (8 * kb + j) % 10);
+                dst[j] = v.x;
+                dst[j + 1] = v.y;
+            }
         };
         uintx4 bf[2][3];  // [buffer][hi, mid, lo] B operands: k-block kb multiplies while kb+1 is being split
         gather(0, y[0]);
