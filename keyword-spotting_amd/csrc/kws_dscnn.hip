@@ -25,7 +25,8 @@
 // channel.  Lane l supplies B[k = 8(l>>5) + e][j = l&31], e = 0..7: it computes the depthwise output of column j
 // for input channels 16m + 8(l>>5) + e itself (m = k-block), splits the eight values into bf16 pieces and feeds
 // them to the matrix core without touching LDS; A = pre-split weights from a two-k-block register ring.
-// (f32 path, 32x32x2: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31], channels 2s + (l>>5).)
+// (f32 path, 32x32x2: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; its 32 k-steps walk the
+// same channels in the same order.)
 // D: column = lane&31 (position), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (output channel).
 //
 // Stencil with 3 LDS reads instead of 9.  The 32 MFMA columns of a tile are 30 consecutive output
@@ -172,7 +173,9 @@ __device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, c
 }
 
 // Pointwise weights of the running block as MFMA A operands.
-//   f32 path   (32x32x2 f32):   wa[ct][s] = W[cout = ct*32 + (l&31)][cin = 2s + (l>>5)], held for the whole block.
+//   f32 path   (32x32x2 f32):   wa[ct][s] = W[cout = ct*32 + (l&31)][cin = 16(s>>3) + 8(l>>5) + (s&7)], held for the
+//     whole block (the K order of the f32 MFMA steps is free; this one is the lane -> channel walk of the split
+//     path, so every variant shares the depthwise stage).
 //   split path (32x32x16 bf16): piece p (0 hi, 1 mid, 2 lo) of W[cout = ct*32 + (l&31)][cin = 16m + 8(l>>5) + j],
 //     j = 0..7 -- eight bf16 per lane and (ct, m, p), pre-split on the host (exactly: hi + mid + lo == W).  Only
 //     two k-blocks m are in registers at a time: ring[m & 1] is fetched one k-block ahead from global memory
@@ -189,11 +192,11 @@ struct PwRegs<true> {
 template <int MODE>
 using PwOperands = PwRegs<(MODE >= 4)>;
 __device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) {
-    const float* pw = w.pw_w + (n - 1) * CH * CH + (lane >> 5) * CH + (lane & 31);
+    const float* pw = w.pw_w + (n - 1) * CH * CH + 8 * (lane >> 5) * CH + (lane & 31);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[2 * s * CH + ct * 32];
+        for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[(16 * (s >> 3) + (s & 7)) * CH + ct * 32];
 }
 __device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, AFrag& f) {
     const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
@@ -391,7 +394,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 
     // accumulator rows 4q..4q+3 of tile ct are output channels ct*32 + 8q + 4*half + (0..3): one float4
     const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
-    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * (SPLIT ? 24 : 3);
+    // lane (column, half) walks the input channels 16m + 8*half + j (m = 0..3, j = 0..7) in 32 steps s = 8m + j
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;
     float psum[2][16];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -416,7 +420,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
             const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
             const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
-            tlo[dh + 1] = G::OFF_IN + pidx(half * (SPLIT ? 8 : 1), a, G::SIN);
+            tlo[dh + 1] = G::OFF_IN + pidx(half * 8, a, G::SIN);
             thi[dh + 1] = tlo[dh + 1] + 32 * G::SIN;
             asm volatile("" : "+v"(tlo[dh + 1]));
             asm volatile("" : "+v"(thi[dh + 1]));
@@ -426,21 +430,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
             float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
         };
-        auto cs_of = [](int s) { return SPLIT ? 16 * (s >> 3) + (s & 7) : 2 * s; };  // channel of step s minus the half's offset
-        auto dw_load = [&](int s, Taps& tp) {
-            const int cs = cs_of(s);
-            tp.q0 = dwt4[cs * 3 + 0];
-            tp.q1 = dwt4[cs * 3 + 1];
-            tp.q2 = dwt4[cs * 3 + 2];
-            const int* ta = cs < 32 ? tlo : thi;
-            // offset of channel (base channel + cs&31) relative to the base: the f32 / VALU walk (base parity =
-            // half, step 2) stays on one member of a pair; the split walk starts on an even channel
-            const int o = SPLIT ? pidx(cs & 31, 0, G::SIN) : (cs & 31) * G::SIN;
-            tp.up = lds[ta[0] + o];
-            tp.mid = lds[ta[1] + o];
-            tp.dn = lds[ta[2] + o];
-        };
-        // split path: the own-column inputs of channels (cs, cs+1), cs even, in three 8-byte reads
+        auto cs_of = [](int s) { return 16 * (s >> 3) + (s & 7); };  // channel of step s minus the half's offset 8*half
+        // the own-column inputs of channels (cs, cs+1), cs even, in three 8-byte reads (pair-interleaved planes)
         struct TapPair {
             float2 up, mid, dn;
         };
@@ -453,6 +444,11 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 tp.dn = *reinterpret_cast<const float2*>(lds + ta[2] + o);
             }
             tp.mid = *reinterpret_cast<const float2*>(lds + ta[1] + o);
+        };
+        auto take = [](Taps& tp, const TapPair& tq, int odd) {  // step 2sp + odd of the pair
+            tp.up = odd ? tq.up.y : tq.up.x;
+            tp.mid = odd ? tq.mid.y : tq.mid.x;
+            tp.dn = odd ? tq.dn.y : tq.dn.x;
         };
         auto wts_load = [&](int s, Taps& tp) {
             const int cs = cs_of(s);
@@ -476,18 +472,13 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             }
             // software pipeline, two steps deep: reads of step s+2 are issued before step s is evaluated
             Taps ta0, ta1;
-            TapPair tq0, tq1;  // split path: inputs of step pairs, two pairs in flight
-            if constexpr (SPLIT) {
-                if constexpr (!NO_STENCIL) {
-                    wts_load(0, ta0);
-                    wts_load(1, ta1);
-                }
-                tap_pair_load(0, tq0);
-                tap_pair_load(1, tq1);
-            } else {
-                dw_load(0, ta0);
-                dw_load(1, ta1);
+            TapPair tq0, tq1;  // inputs of step pairs, two pairs in flight
+            if constexpr (!NO_STENCIL) {
+                wts_load(0, ta0);
+                wts_load(1, ta1);
             }
+            tap_pair_load(0, tq0);
+            tap_pair_load(1, tq1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (SPLIT) {
                 // eight depthwise outputs fill one k-block of 16 input channels (8 per half-wave); they are split
@@ -514,9 +505,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     TapPair& tq = (s & 2) ? tq1 : tq0;  // step pair s >> 1
                     const bool feed = m > 0 && j < 6;
                     if (feed) product(0, m - 1, j);
-                    tp.up = (s & 1) ? tq.up.y : tq.up.x;
-                    tp.mid = (s & 1) ? tq.mid.y : tq.mid.x;
-                    tp.dn = (s & 1) ? tq.dn.y : tq.dn.x;
+                    take(tp, tq, s & 1);
                     y[j] = NO_STENCIL ? tp.mid : dw_eval(tp);
                     __builtin_amdgcn_sched_barrier(0);
                     if (feed) product(1, m - 1, j);
@@ -549,33 +538,32 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             } else {
                 auto& wa = pwo.wa;
 #pragma unroll
-                for (int s = 0; s < 32; s += 2) {
-                    if constexpr (MODE == 1) {
-                        const float y0 = dw_eval(ta0);
-                        if (s + 2 < 32) dw_load(s + 2, ta0);
+                for (int s = 0; s < 32; s += 2) {  // one pair of k-steps per iteration
+                    TapPair& tq = (s & 2) ? tq1 : tq0;
+                    take(ta0, tq, 0);
+                    take(ta1, tq, 1);
+                    float y0, y1;
+                    if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
+                        y0 = ta0.mid;
+                        y1 = ta1.mid;
+                    } else {
+                        y0 = dw_eval(ta0);
+                        y1 = dw_eval(ta1);
+                        if (s + 2 < 32) {
+                            wts_load(s + 2, ta0);
+                            wts_load(s + 3, ta1);
+                        }
+                        if (s + 4 < 32) tap_pair_load((s >> 1) + 2, tq);
                         __builtin_amdgcn_sched_barrier(0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
-                        const float y1 = dw_eval(ta1);
-                        if (s + 3 < 32) dw_load(s + 3, ta1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
-                    } else if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
-                        const float y0 = ta0.mid, y1 = ta1.mid;
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
-                    } else {  // MODE 3, timing ablation: stencil only (results are wrong)
-                        const float y0 = dw_eval(ta0);
-                        if (s + 2 < 32) dw_load(s + 2, ta0);
-                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (MODE == 3) {  // timing ablation: stencil only (results are wrong)
                         acc0[0] += y0 * wa[0][s];
-                        const float y1 = dw_eval(ta1);
-                        if (s + 3 < 32) dw_load(s + 3, ta1);
-                        __builtin_amdgcn_sched_barrier(0);
                         acc1[0] += y1 * wa[1][s + 1];
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], y0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], y0, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s + 1], y1, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s + 1], y1, acc1, 0, 0, 0);
                     }
                 }
             }
@@ -616,16 +604,22 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             const float* pw_w = w.pw_w + (N - 1) * CH * CH;
             float y[32];
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int s = 0; s < 32; s += 2) {
+                TapPair tq;
+                tap_pair_load(s >> 1, tq);
                 Taps tp;
-                dw_load(s, tp);
+                wts_load(s, tp);
+                take(tp, tq, 0);
                 y[s] = dw_eval(tp);
+                wts_load(s + 1, tp);
+                take(tp, tq, 1);
+                y[s + 1] = dw_eval(tp);
             }
 #pragma unroll 1
             for (int co = 0; co < CH; ++co) {
                 float part = 0.f;
 #pragma unroll
-                for (int s = 0; s < 32; ++s) part = fmaf(pw_w[(2 * s + half) * CH + co], y[s], part);
+                for (int s = 0; s < 32; ++s) part = fmaf(pw_w[(16 * (s >> 3) + 8 * half + (s & 7)) * CH + co], y[s], part);
                 const float tot = relu(part + __shfl_xor(part, 32, 64) + pwb[co]);
                 if constexpr (N < 4) {
                     if (valid && half == 0) zout[pidx(co, pos, G::SOUT)] = tot;
