@@ -143,8 +143,8 @@ int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_log
 int kws_stream_open(kws_ctx* ctx, int n_streams);
 int kws_stream_close(kws_ctx* ctx);
 /* d_hop: int16 [n_streams, frame_step] new samples; d_logits float32 [n_streams, C] (NULL: features only);
- * d_label int32 [n_streams] or NULL.  use_graph != 0 replays the three launches of a push (frame kernel,
- * hop counter, DS-CNN) as one hipGraph (built on first use for the given pointer triple). */
+ * d_label int32 [n_streams] or NULL.  A push is two launches (frame kernel, which also advances the hop counter,
+ * and DS-CNN); use_graph != 0 replays them as one hipGraph (built on first use for the given pointer triple). */
 int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
  * by the context) and the number of pushes so far; the newest frame is row (hops - 3) mod num_frames. */

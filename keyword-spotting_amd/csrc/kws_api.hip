@@ -622,14 +622,14 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     const size_t feat_b = sizeof(float) * (size_t)n_streams * p.num_frames * p.numcep;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_pcm_ring), pcm_b) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_feat_ring), feat_b) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_hops), sizeof(int)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&c->d_hops), 2 * sizeof(int)) != hipSuccess) {
         stream_free(c);
         return fail(c, KWS_ENOMEM, "kws_stream_open: device allocation failed");
     }
     c->n_streams = n_streams;
     HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, 2 * sizeof(int), c->stream));
     return KWS_OK;
 }
 
@@ -656,13 +656,13 @@ int kws_stream_smooth_f32(kws_ctx* c, const float* d_logits, int C, int window, 
         const size_t ring_b = sizeof(float) * (size_t)c->n_streams * window * C, sum_b = sizeof(float) * (size_t)c->n_streams * C;
         if (hipMalloc(reinterpret_cast<void**>(&c->d_post_ring), ring_b) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&c->d_post_sum), sum_b) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&c->d_post_count), sizeof(int)) != hipSuccess) {
+            hipMalloc(reinterpret_cast<void**>(&c->d_post_count), 2 * sizeof(int)) != hipSuccess) {
             smooth_free(c);
             return fail(c, KWS_ENOMEM, "kws_stream_smooth_f32: device allocation failed");
         }
         HIP_TRY(c, hipMemsetAsync(c->d_post_ring, 0, ring_b, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_post_sum, 0, sum_b, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_post_count, 0, sizeof(int), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_post_count, 0, 2 * sizeof(int), c->stream));
         c->post_window = window;
         c->post_classes = C;
     }
@@ -683,8 +683,6 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
     hipError_t e = launch_stream_frame(c->stream, c->fp, c->ft, d_hop, c->n_streams, c->d_pcm_ring, c->ring_len,
                                        c->d_feat_ring, c->d_hops);
     if (e != hipSuccess) return e;
-    e = launch_stream_tick(c->stream, c->d_hops);
-    if (e != hipSuccess) return e;
     if (d_logits)
         e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, c->pw_math, nullptr, c->d_hops);
     return e;
@@ -701,7 +699,7 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
     }
     HIP_TRY(c, hipSetDevice(c->device));
     if (use_graph) {
-        // one hipGraph per (hop, logits, label) pointer triple: the three launches replay as one submission
+        // one hipGraph per (hop, logits, label) pointer triple: the two launches replay as one submission
         if (!c->stream_graph || c->graph_key[0] != d_hop || c->graph_key[1] != d_logits || c->graph_key[2] != d_label) {
             if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
             c->stream_graph = nullptr;

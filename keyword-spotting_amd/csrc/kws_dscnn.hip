@@ -887,11 +887,25 @@ __global__ void kws_softmax_f32_kernel(const float* __restrict__ logits, int B, 
 // Moving average of the last `window` posterior vectors per stream (ring [S][window][C], running sum [S][C]),
 // then argmax of the smoothed vector (first maximum wins).  count = hops smoothed so far, before this one.
 __global__ void kws_smooth_posteriors_kernel(const float* __restrict__ logits, int S, int C, int window,
-                                             float* __restrict__ ring, float* __restrict__ sum, const int* __restrict__ count_ptr,
+                                             float* __restrict__ ring, float* __restrict__ sum, int* __restrict__ count_ptr,
                                              float* __restrict__ smoothed, int32_t* __restrict__ label) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const int count = *count_ptr;
+    const int count = count_ptr[0];
+    // every workgroup has read the hop count; the one that finishes last advances it (count_ptr[1] = done counter)
+    auto finish = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(&count_ptr[1], 1) == (int)gridDim.x - 1) {
+                count_ptr[1] = 0;
+                count_ptr[0] = count + 1;
+            }
+        }
+    };
+    if (s >= S) {
+        finish();
+        return;
+    }
     const int slot = count % window;
     float p[MAX_CLASSES];
     softmax_row(logits + (size_t)s * C, C, p);
@@ -913,10 +927,7 @@ __global__ void kws_smooth_posteriors_kernel(const float* __restrict__ logits, i
         }
     }
     if (label) label[s] = arg;
-}
-
-__global__ void kws_tick_kernel(int* counter) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) counter[0] += 1;
+    finish();
 }
 
 }  // namespace
@@ -930,7 +941,6 @@ hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label) {
     hipLaunchKernelGGL(kws_smooth_posteriors_kernel, dim3((S + 63) / 64), dim3(64), 0, s, d_logits, S, C, window, d_ring, d_sum,
                        d_count, d_smoothed, d_label);
-    hipLaunchKernelGGL(kws_tick_kernel, dim3(1), dim3(64), 0, s, d_count);
     return hipGetLastError();
 }
 

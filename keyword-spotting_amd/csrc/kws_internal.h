@@ -73,9 +73,9 @@ hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const Fronten
                            const float* d_wav, int B, float* d_out);
 size_t mfcc_lds_bytes(const FrontendParams& p);
 // Streaming: one hop of frame_step new samples per stream -> one new MFCC frame per stream in the feature ring.
+// d_hops: int[2] = {hops pushed so far, finished-workgroup counter}; the kernel advances the hop count itself.
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
-                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, const int* d_hops);
-hipError_t launch_stream_tick(hipStream_t s, int* d_hops);
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops);
 // Training-time augmentation on the device (time shift, silence, background mix).
 hipError_t launch_augment(hipStream_t s, const int16_t* d_wav, int B, int n, const int32_t* d_shift, const float* d_bg,
                           int bg_len, const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence,

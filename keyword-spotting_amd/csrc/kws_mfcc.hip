@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
                                                               const int16_t* __restrict__ hop, int n_streams,
                                                               int16_t* __restrict__ pcm_ring, int ring_len,
                                                               float* __restrict__ feat_ring,
-                                                              const int* __restrict__ hops_ptr) {
+                                                              int* __restrict__ hops_ptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nfp = (p.nfilt + 3) & ~3;
     float* dctb = reinterpret_cast<float*>(smem);
@@ -642,10 +642,15 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
         pcm_ring[(size_t)sa * ring_len + pos] = hop[(size_t)sa * step + i];
         if (has_b) pcm_ring[(size_t)sb * ring_len + pos] = hop[(size_t)sb * step + i];
     }
-}
-
-__global__ void kws_stream_tick_kernel(int* hops) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) hops[0] += 1;
+    // hop counter: every workgroup read hops_ptr[0] at its start; the one that finishes last advances it
+    // (hops_ptr[1] counts finished workgroups), so no separate one-thread launch is needed
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(&hops_ptr[1], 1) == (int)gridDim.x - 1) {
+            hops_ptr[1] = 0;
+            hops_ptr[0] = hops + 1;
+        }
+    }
 }
 
 // Augmentation of the reference's training transform (kws/libs/audio_processor.py:151-159, 172-233) for a whole
@@ -706,16 +711,11 @@ hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const Fronten
 }
 
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
-                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, const int* d_hops) {
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops) {
     const int nfp = (p.nfilt + 3) & ~3;
     const size_t lds = sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES;
     hipLaunchKernelGGL(kws_stream_frame_kernel, dim3((n_streams + 1) / 2), dim3(64), lds, s, p, t, d_hop, n_streams,
                        d_pcm_ring, ring_len, d_feat_ring, d_hops);
-    return hipGetLastError();
-}
-
-hipError_t launch_stream_tick(hipStream_t s, int* d_hops) {
-    hipLaunchKernelGGL(kws_stream_tick_kernel, dim3(1), dim3(64), 0, s, d_hops);
     return hipGetLastError();
 }
 

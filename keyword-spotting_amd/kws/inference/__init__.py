@@ -135,7 +135,7 @@ class StreamingSpotter:
     The reference's live path captures a VAD-segmented utterance, writes a wav and classifies it once
     (``kws/inference/inference_local.py:114-192``).  Here every ``push`` of ``frame_step`` new samples per
     stream adds one MFCC frame to a 99-frame ring on the GPU and re-classifies the last second of every
-    stream (``kws_stream_push_i16``); with ``use_graph`` the three launches of a push replay as one hipGraph.
+    stream (``kws_stream_push_i16``); with ``use_graph`` the two launches of a push replay as one hipGraph.
     """
 
     def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
