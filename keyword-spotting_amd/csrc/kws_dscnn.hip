@@ -683,8 +683,25 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 2] = __builtin_amdgcn_s_memrealtime();
     stamp();  // 0: start
 
-    // ---- phase 0: weight loads in flight, MFCC map -> zero-padded [103][14] in LDS ------------------
+    // ---- phase 0: MFCC map -> zero-padded [103][14] in LDS, weight loads in flight --------------------
+    // The feature map and block 1's tables are on the critical path of this phase: their loads are issued first
+    // (vector memory returns in order), the conv1 operands behind them.
     constexpr bool SPLIT = MODE >= 4;
+    float* featp = lds + OFF_FEAT;
+    const float* f = feat + (size_t)clip * (IN_T * IN_F);
+    constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
+    float fv[FV];
+    // streaming: the feature map is a ring of IN_T frames; after `hops` pushes the newest frame sits in row
+    // (hops - 3) mod IN_T and the window starts one row after it
+    const int head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
+#pragma unroll
+    for (int k = 0; k < FV; ++k) {
+        const int i = tid + k * NT;
+        fv[k] = i < IN_T * IN_F ? f[((i / IN_F + head) % IN_T) * IN_F + i % IN_F] : 0.f;
+    }
+    BlockTables t1;
+    fetch_block_tables(w, 1, tid, t1);
+    __builtin_amdgcn_sched_barrier(0);
     float a1[SPLIT ? 1 : 50];       // conv1 weights of this wave's output-channel tile (f32 MFMA A operands)
     uintx4 c1f[SPLIT ? 7 : 1][3];   // the same as bf16 pieces (split path)
     PwOperands<MODE> wa;            // pointwise operands of the running block
@@ -700,24 +717,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         for (int s = 0; s < 50; ++s) a1[s] = w.c1_w[(2 * s + half) * CH + ct * 32 + col];
         load_pointwise(w, 1, lane, wa);
     }
-    float* featp = lds + OFF_FEAT;
-    const float* f = feat + (size_t)clip * (IN_T * IN_F);
-    constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
-    float fv[FV];
-    // streaming: the feature map is a ring of IN_T frames; after `hops` pushes the newest frame sits in row
-    // (hops - 3) mod IN_T and the window starts one row after it
-    const int head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
-#pragma unroll
-    for (int k = 0; k < FV; ++k) {
-        const int i = tid + k * NT;
-        fv[k] = i < IN_T * IN_F ? f[((i / IN_F + head) % IN_T) * IN_F + i % IN_F] : 0.f;
-    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
-    {
-        BlockTables t1;
-        fetch_block_tables(w, 1, tid, t1);
-        store_block_tables(lds, 1, tid, t1);
-    }
+    store_block_tables(lds, 1, tid, t1);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FV; ++k) {
