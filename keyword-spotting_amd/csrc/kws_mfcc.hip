@@ -129,7 +129,10 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
     wave_lds_order();
     dft8(v);  // over a -> c
 #pragma unroll
-    for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], tw2[q * 8 + i]);  // W64^(b*c)
+    // W64^(b*c).  The table is symmetric (W64^(q*i)): read as tw2[i][q], the eight distinct addresses of one
+    // instruction are one contiguous 64-byte run (conflict-free); read as tw2[q][i] they are 64 bytes apart and
+    // collide four ways (measured: ~100 LDS cycles per frame pair, a fifth of the kernel's LDS time).
+    for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], tw2[i * 8 + q]);
     const int sw = k1 & 3;  // column swizzle of the second exchange, in units of complex pairs
 #pragma unroll
     for (int c = 0; c < 8; ++c) xbuf[k1 * XROW + 8 * c + (q ^ (2 * sw))] = v[c];
