@@ -152,6 +152,17 @@ int kws_stream_state(kws_ctx* ctx, const float** d_feat_ring, int* hops);
 /* Copy the raw feature ring (float32 [n_streams, num_frames, numcep], ring order) into caller memory. */
 int kws_stream_copy_features(kws_ctx* ctx, float* d_out);
 
+/* ---- cnn-trad-fpool3 (build-defined: the reference only names the model, test.py:80) ----
+ * Sainath & Parada's cnn-trad-fpool3 on the [1,99,10] MFCC map with SAME padding: conv 64 x (20x8) + ReLU,
+ * max-pool 1x3 over frequency, conv 64 x (10x4) + ReLU, flatten, Linear 32, Linear 128 + ReLU, Linear C.
+ * blob = the ten state_dict tensors in order, float32: conv1.weight [64,1,20,8], conv1.bias [64], conv2.weight
+ * [64,64,10,4], conv2.bias [64], lin.weight [32,19008], lin.bias [32], dnn.weight [128,32], dnn.bias [128],
+ * fc.weight [C,128], fc.bias [C] (host pointer, copied). */
+int kws_load_cnn_trad(kws_ctx* ctx, const float* blob, size_t n_floats, int num_classes);
+/* float32 [B,1,99,10] features -> logits float32 [B,C] and labels int32 [B] (d_label may be NULL).  The
+ * convolution output (76 KB per clip) goes through a context workspace that grows on demand. */
+int kws_forward_cnn_trad_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
+
 /* ---- posteriors (build-defined: the reference's scripts stop at argmax of the logits,
  * kws/libs/training.py:371) ------------------------------------------------------------------------------ */
 

@@ -144,6 +144,12 @@ struct kws_ctx {
     DscnnWeights mw{};
     bool model_ready = false;
     int pw_math = KWS_PW_SPLIT_BF16;  // kernel variant of the product entry points
+    // cnn-trad-fpool3
+    void* d_cnntrad = nullptr;
+    CnnTradWeights tw{};
+    bool cnntrad_ready = false;
+    float* d_conv_ws = nullptr;
+    size_t conv_ws_floats = 0;
 
     // workspace (MFCC features between the two kernels of kws_infer_i16)
     float* d_feat_ws = nullptr;
@@ -242,6 +248,7 @@ int kws_create(kws_ctx** out, int device_id) {
     e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = dscnn_init_device();
+    if (e == hipSuccess) e = cnntrad_init_device();
     if (e != hipSuccess) {
         int rc = fail_hip(nullptr, e, "kws_create");
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -270,6 +277,11 @@ void kws_destroy(kws_ctx* c) {
         }
     if (c->d_fe) (void)hipFree(c->d_fe);
     if (c->d_model) (void)hipFree(c->d_model);
+    if (c->d_cnntrad) (void)hipFree(c->d_cnntrad);
+    if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
+    if (c->d_post_ring) (void)hipFree(c->d_post_ring);
+    if (c->d_post_sum) (void)hipFree(c->d_post_sum);
+    if (c->d_post_count) (void)hipFree(c->d_post_count);
     if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
     if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
     if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
@@ -630,6 +642,125 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, 2 * sizeof(int), c->stream));
+    return KWS_OK;
+}
+
+// Exact bf16 hi/mid/lo pieces of eight weights, OR-ed into four dwords per piece (MFMA operand fragment of one lane).
+static void pack_split8(const float (&v)[8], uint32_t* hi, uint32_t* mid, uint32_t* lo) {
+    uint32_t* dst[3] = {hi, mid, lo};
+    for (int j = 0; j < 8; ++j) {
+        float r = v[j];
+        for (int p = 0; p < 3; ++p) {
+            uint32_t u;
+            memcpy(&u, &r, 4);
+            u &= 0xffff0000u;
+            float t;
+            memcpy(&t, &u, 4);
+            r -= t;
+            dst[p][j >> 1] |= (u >> 16) << (16 * (j & 1));
+        }
+    }
+}
+
+int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_classes) {
+    if (!c) return KWS_EINVAL;
+    if (!blob) return fail(c, KWS_EINVAL, "kws_load_cnn_trad: blob is NULL");
+    if (num_classes < 1 || num_classes > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_load_cnn_trad: num_classes must be in [1, 64]");
+    const size_t FLAT = 64 * 297;
+    const size_t n_c1 = 64 * 160, n_c2 = 64 * 64 * 40, n_lin = 32 * FLAT, n_dnn = 128 * 32, n_fc = (size_t)num_classes * 128;
+    const size_t expect = n_c1 + 64 + n_c2 + 64 + n_lin + 32 + n_dnn + 128 + n_fc + num_classes;
+    if (n_floats != expect) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "kws_load_cnn_trad: expected %zu floats for %d classes, got %zu", expect, num_classes, n_floats);
+        return fail(c, KWS_EINVAL, msg);
+    }
+    const float *w1 = blob, *b1 = w1 + n_c1, *w2 = b1 + 64, *b2 = w2 + n_c2, *wl = b2 + 64, *bl = wl + n_lin, *wd = bl + 32,
+                *bd = wd + n_dnn, *wf = bd + 128, *bf = wf + n_fc;
+    // device image (units: 32-bit words): c1_split | c2_split | c1_b | c2_b | lin_wt | lin_b | dnn_w | dnn_b | fc_w | fc_b
+    const size_t o_c1s = 0, o_c2s = o_c1s + 10 * 2 * 3 * 64 * 4, o_c1b = o_c2s + (size_t)40 * 4 * 2 * 3 * 64 * 4, o_c2b = o_c1b + 64,
+                 o_lin = o_c2b + 64, o_linb = o_lin + n_lin, o_dnn = o_linb + 32, o_dnnb = o_dnn + n_dnn, o_fc = o_dnnb + 128,
+                 o_fcb = o_fc + n_fc, total = o_fcb + num_classes;
+    std::vector<uint32_t> h(total, 0u);
+    auto put = [&](size_t off, const float* src, size_t n) { memcpy(&h[off], src, n * sizeof(float)); };
+    // conv1: lane l of (kb, ct): cout = 32ct + (l&31), kernel row 2kb + (l>>5), kernel columns j = 0..7
+    for (int kb = 0; kb < 10; ++kb)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int l = 0; l < 64; ++l) {
+                float v[8];
+                const int co = 32 * ct + (l & 31), kh = 2 * kb + (l >> 5);
+                for (int j = 0; j < 8; ++j) v[j] = w1[(co * 20 + kh) * 8 + j];
+                uint32_t* base = &h[o_c1s + ((size_t)(kb * 2 + ct) * 3 * 64 + l) * 4];
+                pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+            }
+    // conv2: lane l of (kk = kh*4 + kw, cb, ct): cout = 32ct + (l&31), input channels 16cb + 8(l>>5) + j
+    for (int kk = 0; kk < 40; ++kk)
+        for (int cb = 0; cb < 4; ++cb)
+            for (int ct = 0; ct < 2; ++ct)
+                for (int l = 0; l < 64; ++l) {
+                    float v[8];
+                    const int co = 32 * ct + (l & 31), kh = kk >> 2, kw = kk & 3;
+                    for (int j = 0; j < 8; ++j) v[j] = w2[((co * 64 + 16 * cb + 8 * (l >> 5) + j) * 10 + kh) * 4 + kw];
+                    uint32_t* base = &h[o_c2s + ((((size_t)kk * 4 + cb) * 2 + ct) * 3 * 64 + l) * 4];
+                    pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+                }
+    put(o_c1b, b1, 64);
+    put(o_c2b, b2, 64);
+    {
+        float* lt = reinterpret_cast<float*>(&h[o_lin]);  // [19008][32]
+        for (size_t o = 0; o < 32; ++o)
+            for (size_t k = 0; k < FLAT; ++k) lt[k * 32 + o] = wl[o * FLAT + k];
+    }
+    put(o_linb, bl, 32);
+    put(o_dnn, wd, n_dnn);
+    put(o_dnnb, bd, 128);
+    put(o_fc, wf, n_fc);
+    put(o_fcb, bf, num_classes);
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), total * sizeof(uint32_t)) != hipSuccess)
+        return fail(c, KWS_ENOMEM, "kws_load_cnn_trad: device allocation failed");
+    hipError_t e = hipMemcpy(d, h.data(), total * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(c, e, "kws_load_cnn_trad: hipMemcpy");
+    }
+    if (c->d_cnntrad) (void)hipFree(c->d_cnntrad);
+    c->d_cnntrad = d;
+    const float* df = reinterpret_cast<const float*>(d);
+    c->tw.c1_split = d + o_c1s;
+    c->tw.c2_split = d + o_c2s;
+    c->tw.c1_b = df + o_c1b;
+    c->tw.c2_b = df + o_c2b;
+    c->tw.lin_wt = df + o_lin;
+    c->tw.lin_b = df + o_linb;
+    c->tw.dnn_w = df + o_dnn;
+    c->tw.dnn_b = df + o_dnnb;
+    c->tw.fc_w = df + o_fc;
+    c->tw.fc_b = df + o_fcb;
+    c->tw.num_classes = num_classes;
+    c->cnntrad_ready = true;
+    return KWS_OK;
+}
+
+int kws_forward_cnn_trad_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label) {
+    int rc = check_batch(c, d_feat, B, "kws_forward_cnn_trad_f32");
+    if (rc) return rc;
+    if (!d_logits) return fail(c, KWS_EINVAL, "kws_forward_cnn_trad_f32: d_logits is NULL");
+    if (!c->cnntrad_ready) return fail(c, KWS_ESTATE, "kws_forward_cnn_trad_f32: no model loaded (kws_load_cnn_trad)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t need = (size_t)B * 64 * 297;
+    if (need > c->conv_ws_floats) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float* d = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d), need * sizeof(float)) != hipSuccess)
+            return fail(c, KWS_ENOMEM, "kws_forward_cnn_trad_f32: workspace allocation failed");
+        if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
+        c->d_conv_ws = d;
+        c->conv_ws_floats = need;
+    }
+    HIP_TRY(c, launch_cnntrad(c->stream, c->tw, d_feat, B, c->d_conv_ws, d_logits, d_label));
     return KWS_OK;
 }
 

@@ -1,0 +1,297 @@
+// cnn-trad-fpool3 forward for gfx950 (MI355X) -- a build-defined member of the model zoo (SURVEY.md section 8 f-4;
+// the reference only names it, test.py:80).  Sainath & Parada's "cnn-trad-fpool3" on the reference's [1,99,10] MFCC
+// map with SAME padding:
+//   conv1  1->64, 20 (time) x 8 (freq), pad 9/10 x 3/4, ReLU          -> 64 x 99 x 10
+//   max-pool 1 x 3 over frequency, stride 3 (floor)                    -> 64 x 99 x 3
+//   conv2  64->64, 10 x 4, pad 4/5 x 1/2, ReLU                          -> 64 x 99 x 3
+//   flatten (channel-major, 19 008) -> Linear 32 -> Linear 128 + ReLU -> Linear C ; argmax (first maximum wins)
+// 59.4 M multiply-adds per clip, 82 % of them in conv2.
+//
+// Kernel A (one 512-thread workgroup per clip): both convolutions as implicit GEMMs on the bf16 matrix pipe with
+// the exact three-way bf16 split of kws_split_mfma.h (f32-grade results).  conv1 gathers its f32 im2col operand
+// from the zero-padded map in LDS and splits it on the fly; its ReLU'd, frequency-pooled output is written to LDS
+// ALREADY split, as three bf16 planes [position][input channel], so that conv2's B operand -- eight consecutive
+// input channels of one input position -- is a single aligned ds_read_b128 per piece with no VALU work in the
+// loop.  Taps that fall into the padding read a zero row.  conv2's pre-split weights (983 KB) stream from L2.
+// Kernel B: the three small dense layers, batched over clips on the VALU.
+#include <type_traits>
+
+#include "kws_internal.h"
+#include "kws_split_mfma.h"
+
+namespace kws {
+namespace {
+
+constexpr int CT_T = 99, CT_F = 10, CT_FP = 3, CT_P2 = CT_T * CT_FP;  // 297 pooled positions
+constexpr int CT_K1H = 20, CT_K1W = 8, CT_K2H = 10, CT_K2W = 4;
+constexpr int XP_H = CT_T + CT_K1H - 1, XP_W = CT_F + CT_K1W - 1;      // 118 x 17 zero-padded conv1 input
+constexpr int XP_BYTES = 8192;                                          // >= 118*17*4, keeps the planes 16-byte aligned
+constexpr int PL_POS = CT_P2 + 1;                                       // + one all-zero row for padding taps
+constexpr int PL_STRIDE = CH * 2 + 16;                                  // bytes per position: 128 of channels + 16 of padding, so
+                                                                        // that the 16 lanes of a ds_read_b128 group (consecutive
+                                                                        // positions) fall on 16 different 16-byte bank groups
+                                                                        // (at 128 they collide eight ways: measured LDS-bound)
+constexpr int PLANE_BYTES = PL_POS * PL_STRIDE;                         // one bf16 piece plane [pos][64 cin + pad]
+constexpr int CT_LDS_BYTES = XP_BYTES + 3 * PLANE_BYTES;                // 136 928
+constexpr int CT_NW = 8, CT_NT = CT_NW * 64;
+constexpr int C1_TILES = CT_T / 3;                                      // 33 tiles of 3 time rows x 10 bins (30 of 32 columns)
+constexpr int C2_TILES = (CT_P2 + 31) / 32;                             // 10
+static_assert(CT_T % 3 == 0, "conv1 tiles hold whole time rows");
+static_assert(C2_TILES == 10 && CT_NW == 8, "conv2 tile groups {3,3,2,2} x 2 channel tiles assume 10 tiles on 8 wavefronts");
+static_assert(XP_H * XP_W * 4 <= XP_BYTES, "padded input does not fit its LDS slot");
+
+__device__ __forceinline__ float lane_up(float v) { return from_lane_above(v); }
+
+__global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights w, const float* __restrict__ feat, int B,
+                                                                 float* __restrict__ conv_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xp = reinterpret_cast<float*>(smem);
+    unsigned char* planes = smem + XP_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int clip = blockIdx.x;
+    if (clip >= B) return;
+
+    // ---- stage: zero-padded input map, zero row of the pooled planes ---------------------------------
+    for (int i = tid; i < XP_H * XP_W; i += CT_NT) xp[i] = 0.f;
+    if (tid < 3 * CH / 2) reinterpret_cast<uint32_t*>(planes + (tid / (CH / 2)) * PLANE_BYTES + CT_P2 * PL_STRIDE)[tid % (CH / 2)] = 0u;
+    __syncthreads();
+    for (int i = tid; i < CT_T * CT_F; i += CT_NT)
+        xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = feat[(size_t)clip * (CT_T * CT_F) + i];
+    __syncthreads();
+
+    // ---- conv1 + ReLU + frequency max-pool -> pre-split planes ------------------------------------------
+    // A tile = 3 time rows x 10 bins in columns 0..29.  k-block kb covers kernel rows 2kb (lanes 0..31) and 2kb+1
+    // (lanes 32..63), all 8 kernel columns: the lane's eight B elements are consecutive floats of one padded row.
+    // Wavefront w owns channel tile w & 1 and keeps that tile's 30 pre-split A fragments (120 registers) for the
+    // whole phase -- streamed per tile they would cost 2 MB of L1 traffic per clip -- and walks tiles w>>1, +4, ...
+    {
+        const int ct = wv & 1;
+        uintx4 af[CT_K1H / 2][3];  // [k-block][piece]
+        {
+            const uintx4* asrc = reinterpret_cast<const uintx4*>(w.c1_split) + ct * (3 * 64) + lane;
+#pragma unroll
+            for (int kb = 0; kb < CT_K1H / 2; ++kb)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[kb][pc] = asrc[(kb * 2 * 3 + pc) * 64];
+        }
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = w.c1_b[ct * 32 + row_of(r, half)];
+        const int cc = col < 30 ? col : 29;
+        const int tr = cc / CT_F, f = cc % CT_F;
+        const bool owner = col < 30 && f % 3 == 0 && f < 9;
+        for (int u = wv >> 1; u < C1_TILES; u += CT_NW / 2) {
+            const int t = 3 * u + tr;
+            const float* base = xp + (t + half) * XP_W + f;
+            floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;  // two chains, summed below
+            float y[2][8];
+            auto gather = [&](int kb, float (&dst)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[j] = base[kb * 2 * XP_W + j];
+            };
+            gather(0, y[0]);
+            gather(1, y[1]);
+#pragma unroll
+            for (int kb = 0; kb < CT_K1H / 2; ++kb) {
+                const int cur = kb & 1;
+                uintx4 bh, bm, bl;
+                split3(y[cur], bh, bm, bl);
+                if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
+                // six piece products, smallest first
+                acc = mfma_bf16(af[kb][2], bh, acc);
+                acc2 = mfma_bf16(af[kb][0], bl, acc2);
+                acc = mfma_bf16(af[kb][1], bm, acc);
+                acc2 = mfma_bf16(af[kb][1], bh, acc2);
+                acc = mfma_bf16(af[kb][0], bm, acc);
+                acc2 = mfma_bf16(af[kb][0], bh, acc2);
+            }
+            acc += acc2;
+            // bias, ReLU, max over bins (f, f+1, f+2) via two lane shifts; lanes with f in {0,3,6} own a pooled value
+            const int p = t * CT_FP + f / 3;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float m[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float v = relu(acc[r + e] + bias[r + e]);
+                    const float a = lane_up(v), b = lane_up(a);
+                    m[e] = fmaxf(v, fmaxf(a, b));
+                }
+                if (owner) {  // channels co, co+1 (co even) as one dword per piece
+                    const int co = ct * 32 + row_of(r, half);
+                    const float r0 = m[0] - top16(m[0]), r1 = m[1] - top16(m[1]);
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(planes + p * PL_STRIDE + co * 2);
+                    dst[0] = pack_top16(m[0], m[1]);
+                    dst[PLANE_BYTES / 4] = pack_top16(r0, r1);
+                    dst[2 * PLANE_BYTES / 4] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 + ReLU -> HBM ------------------------------------------------------------------------------
+    // K = 2560 ordered (kh, kw, cin): k-block (kk = kh*4 + kw, cb) covers input channels 16cb..16cb+15 of the input
+    // position (t + kh - 4, fp + kw - 1); lane (column, half) reads its eight channels 16cb + 8half .. +7 of each
+    // piece with one ds_read_b128.  One unit per wavefront, a single round: wavefront w takes channel tile w & 1 and
+    // a group of position tiles -- {0,1,2}, {3,4,5}, {6,7}, {8,9} for w >> 1 = 0..3 -- so that the two wavefronts of
+    // a SIMD (w, w+4) carry 3 + 2 tiles, the same on every SIMD, and the A operands (983 KB of pre-split weights
+    // streaming from L2 through L1, which would otherwise be as busy as the matrix pipe) are fetched once per
+    // k-block for all of the wavefront's tiles.
+    auto conv2_unit = [&](auto ntile_tag, int tile0) {
+        constexpr int NTILE = decltype(ntile_tag)::value;
+        const int ct = wv & 1;
+        int p[NTILE], t[NTILE], fp[NTILE];
+        bool pvalid[NTILE];
+        floatx16 acc[NTILE];
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) {
+            p[i] = (tile0 + i) * 32 + col;
+            pvalid[i] = p[i] < CT_P2;
+            const int pc = pvalid[i] ? p[i] : CT_P2 - 1;
+            t[i] = pc / CT_FP;
+            fp[i] = pc % CT_FP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        const uintx4* asrc = reinterpret_cast<const uintx4*>(w.c2_split) + ct * (3 * 64) + lane;
+        // Pipeline at k-block granularity: the A operands of (kk+1, cb) are requested right after those of (kk, cb)
+        // have been used (four k-blocks ahead of their use, an L2 round trip); the B operands of the next k-block
+        // are read from LDS one k-block ahead.
+        uintx4 af[4][3];         // [cb][piece] of this wavefront's channel tile
+        uintx4 bf[2][NTILE][3];  // [parity of the k-block][tile][piece]
+        auto a_load = [&](int kk, int cb) {
+#pragma unroll
+            for (int pc2 = 0; pc2 < 3; ++pc2) af[cb][pc2] = asrc[(((size_t)kk * 4 + cb) * 2 * 3 + pc2) * 64];
+        };
+        auto b_addr = [&](int kk, int i) -> const unsigned char* {
+            const int kh = kk >> 2, kw = kk & 3;
+            const int tin = t[i] + kh - 4, fin = fp[i] + kw - 1;
+            const bool ok = pvalid[i] && (unsigned)tin < (unsigned)CT_T && (unsigned)fin < (unsigned)CT_FP;
+            const int pin = ok ? tin * CT_FP + fin : CT_P2;
+            return planes + pin * PL_STRIDE + half * 16;
+        };
+        auto b_load = [&](const unsigned char* const (&ba)[NTILE], int cb, uintx4 (&dst)[NTILE][3]) {
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i)
+#pragma unroll
+                for (int pc2 = 0; pc2 < 3; ++pc2) dst[i][pc2] = *reinterpret_cast<const uintx4*>(ba[i] + cb * 32 + pc2 * PLANE_BYTES);
+        };
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) a_load(0, cb);
+        const unsigned char* ba[NTILE];
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) ba[i] = b_addr(0, i);
+        b_load(ba, 0, bf[0]);
+        for (int kk = 0; kk < CT_K2H * CT_K2W; ++kk) {
+            const unsigned char* ba_next[NTILE];
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) ba_next[i] = b_addr(kk + 1 < CT_K2H * CT_K2W ? kk + 1 : kk, i);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int cur = cb & 1;
+                if (cb < 3)
+                    b_load(ba, cb + 1, bf[cur ^ 1]);
+                else
+                    b_load(ba_next, 0, bf[cur ^ 1]);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {  // six piece products, smallest first, tiles interleaved
+                    const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+                    const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
+#pragma unroll
+                    for (int i = 0; i < NTILE; ++i) acc[i] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i]);
+                }
+                if (kk + 1 < CT_K2H * CT_K2W) a_load(kk + 1, cb);
+            }
+#pragma unroll
+            for (int i = 0; i < NTILE; ++i) ba[i] = ba_next[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NTILE; ++i) {
+            if (pvalid[i]) {
+                float* o = conv_out + (size_t)clip * (CH * CT_P2) + p[i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = ct * 32 + row_of(r, half);
+                    o[co * CT_P2] = relu(acc[i][r] + w.c2_b[co]);
+                }
+            }
+        }
+    };
+    {
+        const int g = wv >> 1;
+        if (g < 2)
+            conv2_unit(std::integral_constant<int, 3>{}, 3 * g);
+        else
+            conv2_unit(std::integral_constant<int, 2>{}, 6 + 2 * (g - 2));
+    }
+}
+
+// Kernel B: Linear(19008 -> 32) ; Linear(32 -> 128) + ReLU ; Linear(128 -> C) ; argmax.  8 clips per workgroup:
+// thread (clip slot s = tid >> 5, output o = tid & 31).  lin_wt is the first layer's weight transposed to
+// [19008][32], so a wavefront reads whole 128-byte rows; the 8 clips of a workgroup share them through L1.
+constexpr int CT_FLAT = CH * CT_P2;  // 19008
+constexpr int CT_LIN = 32, CT_DNN = 128;
+__global__ __launch_bounds__(256) void kws_cnntrad_dense_kernel(CnnTradWeights w, const float* __restrict__ conv_out, int B,
+                                                                float* __restrict__ logits, int32_t* __restrict__ label) {
+    __shared__ float h1[8][CT_LIN];
+    __shared__ float h2[8][CT_DNN];
+    __shared__ float lg[8][MAX_CLASSES];
+    const int tid = threadIdx.x, s = tid >> 5, o = tid & 31;
+    const int clip = blockIdx.x * 8 + s;
+    const bool live = clip < B;
+    const float4* x4 = reinterpret_cast<const float4*>(conv_out + (size_t)(live ? clip : 0) * CT_FLAT);
+    float acc = w.lin_b[o];
+    for (int k4 = 0; k4 < CT_FLAT / 4; ++k4) {
+        const float4 x = x4[k4];
+        const float* wr = w.lin_wt + (size_t)k4 * 4 * CT_LIN + o;
+        acc = fmaf(x.x, wr[0], acc);
+        acc = fmaf(x.y, wr[CT_LIN], acc);
+        acc = fmaf(x.z, wr[2 * CT_LIN], acc);
+        acc = fmaf(x.w, wr[3 * CT_LIN], acc);
+    }
+    h1[s][o] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CT_DNN / 32; ++i) {
+        const int j = o + 32 * i;
+        float a = w.dnn_b[j];
+        for (int k = 0; k < CT_LIN; ++k) a = fmaf(h1[s][k], w.dnn_w[j * CT_LIN + k], a);
+        h2[s][j] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    const int C = w.num_classes;
+    for (int c = o; c < C; c += 32) {
+        float a = w.fc_b[c];
+        for (int k = 0; k < CT_DNN; ++k) a = fmaf(h2[s][k], w.fc_w[c * CT_DNN + k], a);
+        lg[s][c] = a;
+        if (live) logits[(size_t)clip * C + c] = a;
+    }
+    __syncthreads();
+    if (o == 0 && live && label) {
+        int arg = 0;
+        float best = lg[s][0];
+        for (int c = 1; c < C; ++c)
+            if (lg[s][c] > best) {
+                best = lg[s][c];
+                arg = c;
+            }
+        label[clip] = arg;
+    }
+}
+
+}  // namespace
+
+hipError_t cnntrad_init_device() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kws_cnntrad_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               CT_LDS_BYTES);
+}
+
+hipError_t launch_cnntrad(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, float* d_logits,
+                          int32_t* d_label) {
+    hipLaunchKernelGGL(kws_cnntrad_conv_kernel, dim3(B), dim3(CT_NT), CT_LDS_BYTES, s, w, d_feat, B, d_conv_ws);
+    hipLaunchKernelGGL(kws_cnntrad_dense_kernel, dim3((B + 7) / 8), dim3(256), 0, s, w, d_conv_ws, B, d_logits, d_label);
+    return hipGetLastError();
+}
+
+}  // namespace kws

@@ -43,13 +43,11 @@
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
 //   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled
 #include "kws_internal.h"
+#include "kws_split_mfma.h"
 
 namespace kws {
 namespace {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
 #ifndef KWS_DSCNN_WAVES
 #define KWS_DSCNN_WAVES 8
@@ -91,13 +89,6 @@ struct Blk {
     static constexpr int BUF = (N - 1) & 1;                       // which depthwise / bias buffer it reads
 };
 
-// one v_max_f32 (the C++ forms compile to a canonicalising v_max plus the real one)
-__device__ __forceinline__ float relu(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
 // Depthwise 3x3 (+bias) at this lane's column from its three own-column inputs: nine multiply-adds and two
 // fused DPP multiply-adds that pull the neighbouring lanes' column sums across the wavefront (0 shifted in at the
 // ends).  Written as one asm block so that (a) the shift and the multiply-add are one instruction each
@@ -127,16 +118,6 @@ __device__ __forceinline__ float stencil3x3(float w0, float w1, float w2, float 
     if constexpr (TO_MFMA) asm volatile("s_nop 1" : "+v"(c));
     return c;
 }
-__device__ __forceinline__ int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// lane i <- lane i-1 / lane i+1 across the whole wavefront (0 shifted in at the ends)
-__device__ __forceinline__ float from_lane_below(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float from_lane_above(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
-}
-
 // Sum over each 32-lane half of the wavefront without touching LDS: inclusive scan inside the 16-lane rows
 // (row_shr 1,2,4,8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15).  Lanes 31 and 63 hold the totals.
 template <int CTRL, int ROW_MASK>
@@ -208,33 +189,6 @@ __device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, 
 // first operands of block n: the whole block (f32) or its k-block 0 (split)
 __device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) { load_pointwise(w, n, lane, o); }
 __device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<true>& o) { load_afrag(w, n, 0, lane, o.ring[0]); }
-
-// Exact three-way split of eight f32 values into bf16 pieces (y == hi + mid + lo, each piece the top 16 bits of
-// the running remainder), packed as MFMA B operands.  bf16 x bf16 products are exact in the matrix core's f32
-// accumulate, so the six products with combined order <= 2 reproduce the f32 product to ~2^-24 relative.
-__device__ __forceinline__ uint32_t pack_top16(float even, float odd) {
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, odd), __builtin_bit_cast(uint32_t, even), 0x07060302u);
-}
-__device__ __forceinline__ float top16(float v) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & 0xffff0000u);
-}
-__device__ __forceinline__ void split3(const float (&y)[8], uintx4& hi, uintx4& mid, uintx4& lo) {
-    float r1[8], r2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r1[j] = y[j] - top16(y[j]);
-        r2[j] = r1[j] - top16(r1[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        hi[i] = pack_top16(y[2 * i], y[2 * i + 1]);
-        mid[i] = pack_top16(r1[2 * i], r1[2 * i + 1]);
-        lo[i] = pack_top16(r2[2 * i], r2[2 * i + 1]);
-    }
-}
-__device__ __forceinline__ floatx16 mfma_bf16(const uintx4& a, const uintx4& b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // conv1: D[cout][pos] = sum_k W[cout][k] * im2col[k][pos], k = kh*10 + kw, as 50 MFMA k-steps.

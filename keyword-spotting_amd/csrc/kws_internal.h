@@ -113,6 +113,25 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
                         const int* d_ring_hops = nullptr);
 
+// ------------------------------------------------------------------------------------------------
+// cnn-trad-fpool3 (build-defined model-zoo member, kws_cnntrad.hip)
+struct CnnTradWeights {
+    const uint32_t* c1_split;  // [kb 10][ct 2][piece 3][lane 64][4]    conv1 20x8 as bf16 hi/mid/lo MFMA A operands
+    const float* c1_b;         // [64]
+    const uint32_t* c2_split;  // [kk 40][cb 4][ct 2][piece 3][lane 64][4]  conv2 10x4x64
+    const float* c2_b;         // [64]
+    const float* lin_wt;       // [19008][32]  first dense layer, transposed
+    const float* lin_b;        // [32]
+    const float* dnn_w;        // [128][32]
+    const float* dnn_b;        // [128]
+    const float* fc_w;         // [C][128]
+    const float* fc_b;         // [C]
+    int num_classes;
+};
+hipError_t cnntrad_init_device();
+hipError_t launch_cnntrad(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, float* d_logits,
+                          int32_t* d_label);
+
 hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label);

@@ -50,6 +50,8 @@ SIGNATURES = {
     "kws_stream_push_i16": (C.c_int, [_c_ctx, _i16p, _f32p, _i32p, C.c_int]),
     "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
+    "kws_load_cnn_trad": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
+    "kws_forward_cnn_trad_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_softmax_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p]),
     "kws_stream_smooth_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p, _i32p]),
     "kws_augment_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_void_p, _f32p, C.c_void_p, _f32p]),
@@ -174,6 +176,15 @@ class Context:
             self._lib.kws_forward_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
             ModelError,
         )
+
+    def load_cnn_trad(self, blob: np.ndarray, num_classes: int):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(self._lib.kws_load_cnn_trad(self._h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, int(num_classes)),
+                    ModelError)
+
+    def forward_cnn_trad_f32(self, feat, logits, label=None):
+        self._check(self._lib.kws_forward_cnn_trad_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits),
+                                                       _ptr(label) if label is not None else None), ModelError)
 
     def softmax_f32(self, logits, prob):
         self._check(self._lib.kws_softmax_f32(self._h, _ptr(logits), int(logits.shape[0]), int(logits.shape[1]), _ptr(prob)),

@@ -197,3 +197,49 @@ class DepthwiseSeparableConvBN(KeywordSpottingModel):
 
     def infer_pcm16(self, wav: torch.Tensor):
         return self.fold().infer_pcm16(wav)
+
+
+class CnnTradFpool3(KeywordSpottingModel):
+    """Build-defined model-zoo member: Sainath & Parada's cnn-trad-fpool3 on the reference's
+    ``[1,99,10]`` MFCC map with SAME padding -- conv 64x(20x8)+ReLU, max-pool 1x3 over frequency, conv 64x(10x4)+ReLU,
+    flatten, Linear 32, Linear 128+ReLU, Linear C.  The modules hold parameters; ``forward`` is
+    ``kws_forward_cnn_trad_f32`` (both convolutions as implicit GEMMs on the bf16 matrix pipe with the exact
+    three-way split, the dense tail batched on the VALU).  Inference only."""
+
+    def __init__(self, num_classes: int = 12):
+        super().__init__(num_classes)
+        self.conv1 = nn.Conv2d(1, 64, kernel_size=(20, 8))
+        self.conv2 = nn.Conv2d(64, 64, kernel_size=(10, 4))
+        self.lin = nn.Linear(64 * 99 * 3, 32)
+        self.dnn = nn.Linear(32, 128)
+        self.fc = nn.Linear(128, num_classes)
+        self._ctx = None
+        self._uploaded = None
+
+    def packed_weights(self) -> np.ndarray:
+        return np.concatenate([v.detach().to("cpu", torch.float32).reshape(-1).numpy() for v in self.state_dict().values()])
+
+    def _context(self, device_index: int):
+        from kws import _native
+
+        if self._ctx is None or self._ctx.device != device_index:
+            self._ctx = _native.Context(device_index, ModelError)
+            self._uploaded = None
+        fp = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if fp != self._uploaded:
+            self._ctx.load_cnn_trad(self.packed_weights(), self.num_classes)
+            self._uploaded = fp
+        self._ctx.use_torch_stream()
+        return self._ctx
+
+    def forward(self, x: torch.Tensor, return_labels: bool = False):
+        if not x.is_cuda:
+            raise ModelError("CnnTradFpool3.forward needs a CUDA/ROCm tensor: the forward is a HIP kernel and has no CPU fallback")
+        if x.dim() != 4 or tuple(x.shape[1:]) != FEATURE_SHAPE:
+            raise ModelError(f"expected input [B,1,99,10], got {tuple(x.shape)}")
+        ctx = self._context(x.device.index or 0)
+        x = x.detach().to(torch.float32).contiguous()
+        logits = torch.empty((x.shape[0], self.num_classes), dtype=torch.float32, device=x.device)
+        labels = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
+        ctx.forward_cnn_trad_f32(x, logits, labels)
+        return (logits, labels) if return_labels else logits

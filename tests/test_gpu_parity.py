@@ -604,3 +604,25 @@ def test_softmax_and_streaming_posterior_smoothing(native, dev):
         assert np.array_equal(labels, want.argmax(axis=1))
     raw.close()
     smo.close()
+
+
+def test_cnn_trad_fpool3_matches_its_cpu_definition(dev):
+    """cnn-trad-fpool3 (build-defined) on the GPU vs oracle.cnn_trad on the CPU: logits within
+    1e-4 relative to their scale, identical argmax where the margin allows, ragged batch (not a multiple of 8)."""
+    from oracle import cnn_trad as o_ct
+    from kws.libs.models import CnnTradFpool3
+
+    state = o_ct.random_state(seed=4)
+    m = CnnTradFpool3(12)
+    m.load_state_dict(state)
+    torch.manual_seed(8)
+    x = torch.randn(21, 1, 99, 10) * 3.0
+    want = o_ct.forward(state, x)
+    logits, labels = m.forward(x.to(dev), return_labels=True)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((logits.cpu() - want).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL * scale).numpy()
+    assert np.array_equal(labels.cpu().numpy()[clear], want.argmax(dim=1).numpy()[clear])
+    assert clear.mean() > 0.8
