@@ -676,9 +676,9 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     }
     const float *w1 = blob, *b1 = w1 + n_c1, *w2 = b1 + 64, *b2 = w2 + n_c2, *wl = b2 + 64, *bl = wl + n_lin, *wd = bl + 32,
                 *bd = wd + n_dnn, *wf = bd + 128, *bf = wf + n_fc;
-    // device image (units: 32-bit words): c1_split | c2_split | c1_b | c2_b | lin_wt | lin_b | dnn_w | dnn_b | fc_w | fc_b
+    // device image (units: 32-bit words): c1_split | c2_split | c1_b | c2_b | lin_split | lin_b | dnn_w | dnn_b | fc_w | fc_b
     const size_t o_c1s = 0, o_c2s = o_c1s + 10 * 2 * 3 * 64 * 4, o_c1b = o_c2s + (size_t)40 * 4 * 2 * 3 * 64 * 4, o_c2b = o_c1b + 64,
-                 o_lin = o_c2b + 64, o_linb = o_lin + n_lin, o_dnn = o_linb + 32, o_dnnb = o_dnn + n_dnn, o_fc = o_dnnb + 128,
+                 o_lin = o_c2b + 64, o_linb = o_lin + (size_t)(FLAT / 16) * 3 * 64 * 4, o_dnn = o_linb + 32, o_dnnb = o_dnn + n_dnn, o_fc = o_dnnb + 128,
                  o_fcb = o_fc + n_fc, total = o_fcb + num_classes;
     std::vector<uint32_t> h(total, 0u);
     auto put = [&](size_t off, const float* src, size_t n) { memcpy(&h[off], src, n * sizeof(float)); };
@@ -705,11 +705,14 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                 }
     put(o_c1b, b1, 64);
     put(o_c2b, b2, 64);
-    {
-        float* lt = reinterpret_cast<float*>(&h[o_lin]);  // [19008][32]
-        for (size_t o = 0; o < 32; ++o)
-            for (size_t k = 0; k < FLAT; ++k) lt[k * 32 + o] = wl[o * FLAT + k];
-    }
+    // first dense layer as MFMA B operands (32x32x16): lane l of k-block kb: output l&31, inputs 16kb + 8(l>>5) + j
+    for (size_t kb = 0; kb < FLAT / 16; ++kb)
+        for (int l = 0; l < 64; ++l) {
+            float v[8];
+            for (int j = 0; j < 8; ++j) v[j] = wl[(size_t)(l & 31) * FLAT + 16 * kb + 8 * (l >> 5) + j];
+            uint32_t* base = &h[o_lin + (kb * 3 * 64 + l) * 4];
+            pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+        }
     put(o_linb, bl, 32);
     put(o_dnn, wd, n_dnn);
     put(o_dnnb, bd, 128);
@@ -733,7 +736,7 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->tw.c2_split = d + o_c2s;
     c->tw.c1_b = df + o_c1b;
     c->tw.c2_b = df + o_c2b;
-    c->tw.lin_wt = df + o_lin;
+    c->tw.lin_split = d + o_lin;
     c->tw.lin_b = df + o_linb;
     c->tw.dnn_w = df + o_dnn;
     c->tw.dnn_b = df + o_dnnb;

@@ -13,7 +13,7 @@
 // ALREADY split, as three bf16 planes [position][input channel], so that conv2's B operand -- eight consecutive
 // input channels of one input position -- is a single aligned ds_read_b128 per piece with no VALU work in the
 // loop.  Taps that fall into the padding read a zero row.  conv2's pre-split weights (983 KB) stream from L2.
-// Kernel B: the three small dense layers, batched over clips on the VALU.
+// Kernel B: the dense tail, 32 clips per workgroup; its 19008 -> 32 layer is a GEMM on the same matrix-pipe path.
 #include <type_traits>
 
 #include "kws_internal.h"
@@ -227,56 +227,94 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
     }
 }
 
-// Kernel B: Linear(19008 -> 32) ; Linear(32 -> 128) + ReLU ; Linear(128 -> C) ; argmax.  8 clips per workgroup:
-// thread (clip slot s = tid >> 5, output o = tid & 31).  lin_wt is the first layer's weight transposed to
-// [19008][32], so a wavefront reads whole 128-byte rows; the 8 clips of a workgroup share them through L1.
+// Kernel B: Linear(19008 -> 32) ; Linear(32 -> 128) + ReLU ; Linear(128 -> C) ; argmax.
+// The first layer is a [clips x 19008] x [19008 x 32] GEMM: 32 clips per workgroup, D[clip][output] on the bf16
+// matrix pipe with the exact split (activations split on the fly, weights pre-split as B operands), K divided
+// among the 12 wavefronts of the workgroup (99 k-blocks of 16 each) and the partial sums combined through LDS.
+// It reads the 76 KB per clip that kernel A wrote: HBM-bound, so loads run three k-blocks ahead in every wave.
 constexpr int CT_FLAT = CH * CT_P2;  // 19008
 constexpr int CT_LIN = 32, CT_DNN = 128;
-__global__ __launch_bounds__(256) void kws_cnntrad_dense_kernel(CnnTradWeights w, const float* __restrict__ conv_out, int B,
-                                                                float* __restrict__ logits, int32_t* __restrict__ label) {
-    __shared__ float h1[8][CT_LIN];
-    __shared__ float h2[8][CT_DNN];
-    __shared__ float lg[8][MAX_CLASSES];
-    const int tid = threadIdx.x, s = tid >> 5, o = tid & 31;
-    const int clip = blockIdx.x * 8 + s;
-    const bool live = clip < B;
-    const float4* x4 = reinterpret_cast<const float4*>(conv_out + (size_t)(live ? clip : 0) * CT_FLAT);
-    float acc = w.lin_b[o];
-    for (int k4 = 0; k4 < CT_FLAT / 4; ++k4) {
-        const float4 x = x4[k4];
-        const float* wr = w.lin_wt + (size_t)k4 * 4 * CT_LIN + o;
-        acc = fmaf(x.x, wr[0], acc);
-        acc = fmaf(x.y, wr[CT_LIN], acc);
-        acc = fmaf(x.z, wr[2 * CT_LIN], acc);
-        acc = fmaf(x.w, wr[3 * CT_LIN], acc);
-    }
-    h1[s][o] = acc;
-    __syncthreads();
+constexpr int DN_WAVES = 12, DN_KB = CT_FLAT / 16 / DN_WAVES;  // 99 k-blocks per wavefront
+static_assert(DN_KB * DN_WAVES * 16 == CT_FLAT, "K must divide evenly among the wavefronts");
+__global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTradWeights w, const float* __restrict__ conv_out, int B,
+                                                                          float* __restrict__ logits, int32_t* __restrict__ label) {
+    __shared__ float part[DN_WAVES][32 * 32];  // partial D of every wavefront, [clip][output]
+    __shared__ float h1[32][CT_LIN];
+    __shared__ float h2[32][CT_DNN];
+    __shared__ float lg[32][MAX_CLASSES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int clip0 = blockIdx.x * 32;
+    {
+        // A operand: lane (row = clip slot col, half) holds x[clip][16kb + 8half .. +7]
+        const int aclip = clip0 + col < B ? clip0 + col : B - 1;
+        const float4* xa = reinterpret_cast<const float4*>(conv_out + (size_t)aclip * CT_FLAT + (size_t)wv * DN_KB * 16 + 8 * half);
+        // B operand: pre-split weights [kb][piece][lane]
+        const uintx4* wb = reinterpret_cast<const uintx4*>(w.lin_split) + (size_t)wv * DN_KB * 3 * 64 + lane;
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        constexpr int DEPTH = 3;
+        float4 xr[DEPTH][2];
+        uintx4 wr[DEPTH][3];
+        auto load = [&](int kb, int slot) {
+            xr[slot][0] = xa[kb * 4];
+            xr[slot][1] = xa[kb * 4 + 1];
 #pragma unroll
-    for (int i = 0; i < CT_DNN / 32; ++i) {
-        const int j = o + 32 * i;
+            for (int pc = 0; pc < 3; ++pc) wr[slot][pc] = wb[(kb * 3 + pc) * 64];
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load(d, d);
+        for (int kb0 = 0; kb0 < DN_KB; kb0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kb = kb0 + d;
+                const float y[8] = {xr[d][0].x, xr[d][0].y, xr[d][0].z, xr[d][0].w, xr[d][1].x, xr[d][1].y, xr[d][1].z, xr[d][1].w};
+                uintx4 ah, am, al;
+                split3(y, ah, am, al);
+                const uintx4 bh = wr[d][0], bm = wr[d][1], bl = wr[d][2];
+                if (kb + DEPTH < DN_KB) load(kb + DEPTH, d);
+                acc = mfma_bf16(al, bh, acc);
+                acc = mfma_bf16(ah, bl, acc);
+                acc = mfma_bf16(am, bm, acc);
+                acc = mfma_bf16(am, bh, acc);
+                acc = mfma_bf16(ah, bm, acc);
+                acc = mfma_bf16(ah, bh, acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wv][row_of(r, half) * 32 + col] = acc[r];  // D row = clip slot, column = output
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * CT_LIN; i += DN_WAVES * 64) {
+        float a = w.lin_b[i & 31];
+#pragma unroll
+        for (int k = 0; k < DN_WAVES; ++k) a += part[k][i];
+        h1[i >> 5][i & 31] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * CT_DNN; i += DN_WAVES * 64) {
+        const int s = i / CT_DNN, j = i % CT_DNN;
         float a = w.dnn_b[j];
         for (int k = 0; k < CT_LIN; ++k) a = fmaf(h1[s][k], w.dnn_w[j * CT_LIN + k], a);
         h2[s][j] = a > 0.f ? a : 0.f;
     }
     __syncthreads();
     const int C = w.num_classes;
-    for (int c = o; c < C; c += 32) {
+    for (int i = tid; i < 32 * C; i += DN_WAVES * 64) {
+        const int s = i / C, c = i % C;
         float a = w.fc_b[c];
         for (int k = 0; k < CT_DNN; ++k) a = fmaf(h2[s][k], w.fc_w[c * CT_DNN + k], a);
         lg[s][c] = a;
-        if (live) logits[(size_t)clip * C + c] = a;
+        if (clip0 + s < B) logits[(size_t)(clip0 + s) * C + c] = a;
     }
     __syncthreads();
-    if (o == 0 && live && label) {
+    if (tid < 32 && clip0 + tid < B && label) {
         int arg = 0;
-        float best = lg[s][0];
+        float best = lg[tid][0];
         for (int c = 1; c < C; ++c)
-            if (lg[s][c] > best) {
-                best = lg[s][c];
+            if (lg[tid][c] > best) {
+                best = lg[tid][c];
                 arg = c;
             }
-        label[clip] = arg;
+        label[clip0 + tid] = arg;
     }
 }
 
@@ -290,7 +328,7 @@ hipError_t cnntrad_init_device() {
 hipError_t launch_cnntrad(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, float* d_logits,
                           int32_t* d_label) {
     hipLaunchKernelGGL(kws_cnntrad_conv_kernel, dim3(B), dim3(CT_NT), CT_LDS_BYTES, s, w, d_feat, B, d_conv_ws);
-    hipLaunchKernelGGL(kws_cnntrad_dense_kernel, dim3((B + 7) / 8), dim3(256), 0, s, w, d_conv_ws, B, d_logits, d_label);
+    hipLaunchKernelGGL(kws_cnntrad_dense_kernel, dim3((B + 31) / 32), dim3(DN_WAVES * 64), 0, s, w, d_conv_ws, B, d_logits, d_label);
     return hipGetLastError();
 }
 

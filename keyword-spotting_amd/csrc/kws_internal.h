@@ -120,7 +120,7 @@ struct CnnTradWeights {
     const float* c1_b;         // [64]
     const uint32_t* c2_split;  // [kk 40][cb 4][ct 2][piece 3][lane 64][4]  conv2 10x4x64
     const float* c2_b;         // [64]
-    const float* lin_wt;       // [19008][32]  first dense layer, transposed
+    const uint32_t* lin_split; // [kb 1188][piece 3][lane 64][4]  first dense layer as bf16 hi/mid/lo MFMA B operands
     const float* lin_b;        // [32]
     const float* dnn_w;        // [128][32]
     const float* dnn_b;        // [128]
