@@ -190,18 +190,32 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const int cur = cb & 1;
-                if (cb < 3)
-                    b_load(ba, cb + 1, bf[cur ^ 1]);
-                else
-                    b_load(ba_next, 0, bf[cur ^ 1]);
+                const bool more = kk + 1 < CT_K2H * CT_K2W;
+                // The loads of the next k-block are spread between the MFMAs (one load behind each matrix
+                // instruction, pinned with scheduling barriers): issued in a lump after them, the matrix pipe drains
+                // while the wavefront works through a dozen memory instructions.  An A piece is re-requested for
+                // (kk+1, cb) right behind its last use: lo after product 0, mid after product 3, hi after product 5.
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {  // six piece products, smallest first, tiles interleaved
                     const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
                     const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
 #pragma unroll
-                    for (int i = 0; i < NTILE; ++i) acc[i] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i]);
+                    for (int i = 0; i < NTILE; ++i) {
+                        acc[i] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int n = q * NTILE + i;  // one B load (tile n / 3, piece n % 3) of the next k-block per MFMA
+                        if (n < 3 * NTILE) {
+                            const unsigned char* src = (cb < 3 ? ba[n / 3] + (cb + 1) * 32 : ba_next[n / 3]) + (n % 3) * PLANE_BYTES;
+                            bf[cur ^ 1][n / 3][n % 3] = *reinterpret_cast<const uintx4*>(src);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (more && (q == 0 || q == 3 || q == 5)) {
+                        const int pc2 = q == 0 ? 2 : q == 3 ? 1 : 0;
+                        af[cb][pc2] = asrc[(((size_t)(kk + 1) * 4 + cb) * 2 * 3 + pc2) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                if (kk + 1 < CT_K2H * CT_K2W) a_load(kk + 1, cb);
             }
 #pragma unroll
             for (int i = 0; i < NTILE; ++i) ba[i] = ba_next[i];
