@@ -36,6 +36,11 @@ PEAK_HBM_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E spec
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16 MFMA
 # bf16 MFMA work the split path executes per clip: (42 block units x 48 + 10 conv1 units x 42) MFMAs of 32x32x16
 DSCNN_EXECUTED_BF16_FLOP_PER_CLIP = (42 * 48 + 10 * 42) * 32 * 32 * 16 * 2
+# cnn-trad-fpool3 (build-defined): the two convolutions of kws_cnntrad_conv_kernel / all five layers
+CNNTRAD_CONV_FLOP_PER_CLIP = 2 * (99 * 10 * 64 * 160 + 297 * 64 * 2560)
+CNNTRAD_FLOP_PER_CLIP = CNNTRAD_CONV_FLOP_PER_CLIP + 2 * (19008 * 32 + 32 * 128 + 128 * NUM_CLASSES)
+# executed on the bf16 pipe: conv1 33 tiles x 2 channel tiles x 10 k-blocks, conv2 10 x 2 x 160, six products each
+CNNTRAD_CONV_EXECUTED_BF16_FLOP_PER_CLIP = (33 * 2 * 10 + 10 * 2 * 160) * 6 * 32 * 32 * 16 * 2
 
 
 def shard_bounds(total: int, world: int, rank: int):
@@ -115,6 +120,56 @@ def cpu_baseline(clips: np.ndarray, blob: np.ndarray):
     }, logits.numpy()
 
 
+def cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, state, logits):
+    """The JSON line of `--model cnn-trad-fpool3` (BASELINE.json configs[2] read literally; not the driver's line)."""
+    c_ms, c_n = ctx.prof_read(_native.KWS_K_CNNTRAD_CONV)
+    d_ms, d_n = ctx.prof_read(_native.KWS_K_CNNTRAD_DENSE)
+    m_ms, m_n = ctx.prof_read(_native.KWS_K_MFCC)
+    conv_s, dense_s, mfcc_s = (c_ms / max(c_n, 1)) * 1e-3, (d_ms / max(d_n, 1)) * 1e-3, (m_ms / max(m_n, 1)) * 1e-3
+    value = B * world * args.steps / elapsed
+    executed = CNNTRAD_CONV_EXECUTED_BF16_FLOP_PER_CLIP * B / conv_s / 1e12 if conv_s > 0 else 0.0
+    out = {
+        "metric": "1s 16kHz clips/sec end-to-end (wav->label)", "value": value, "unit": "clips/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "configs[2] read literally: batch=4096/GPU synthetic uniform int16 1s/16kHz clips, device-resident, "
+                        "MFCC + cnn-trad-fpool3 (build-defined, SAME padding on the 99x10 map, 12 classes, random-init) "
+                        "-> logits+label",
+            "clips_per_gpu_per_step": B,
+            "sharding": f"{world} independent shard(s), no data-path collective",
+        },
+        "roofline": {
+            "kernel": _native.kernel_name(_native.KWS_K_CNNTRAD_CONV), "bound": "mfma",
+            "achieved": executed, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": executed / PEAK_BF16_TFLOPS,
+            "traffic": None, "avg_kernel_ms": conv_s * 1e3, "launches": c_n,
+            "flop_per_clip_executed_bf16": CNNTRAD_CONV_EXECUTED_BF16_FLOP_PER_CLIP,
+            "flop_per_clip_algorithmic": CNNTRAD_CONV_FLOP_PER_CLIP,
+            "algorithmic_tflops": CNNTRAD_CONV_FLOP_PER_CLIP * B / conv_s / 1e12 if conv_s > 0 else 0.0,
+            "math": "f32 in / f32 out; both convolutions on v_mfma_f32_32x32x16_bf16 as exact three-way bf16 splits "
+                    "(6 MFMAs per f32 product); achieved/peak count the bf16 MFMA work executed against the dense bf16 peak",
+        },
+        "other_kernels_ms": {_native.kernel_name(_native.KWS_K_MFCC): mfcc_s * 1e3,
+                             _native.kernel_name(_native.KWS_K_CNNTRAD_DENSE): dense_s * 1e3},
+    }
+    if world == 1 and args.cpu_sample > 0:
+        import torch
+
+        from oracle import cnn_trad as o_ct
+        from oracle import psf_mfcc as o_mfcc
+
+        n = min(args.cpu_sample, B, 256)
+        t0 = time.perf_counter()
+        feats = o_mfcc.collate_pcm16(clips[:n])
+        want = o_ct.forward(state, torch.from_numpy(feats)).numpy()
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n} of the step's clips: oracle MFCC (NumPy, per clip) + torch-CPU cnn-trad-fpool3"}
+        scale = max(1.0, float(np.abs(want).max()))
+        out["parity_vs_cpu_max_abs_logit_err_over_scale"] = float(np.abs(logits[:n].cpu().numpy() - want).max() / scale)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +177,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="clips timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--model", choices=["ds-cnn", "cnn-trad-fpool3"], default="ds-cnn",
+                    help="ds-cnn: the reference's model (the driver's line); cnn-trad-fpool3: the build-defined model "
+                         "BASELINE.json configs[2] names (parity unpinned against the reference, DESIGN.md 4.5)")
     args = ap.parse_args()
 
     import torch
@@ -154,14 +212,23 @@ def main():
     clips = synth_clips(B, seed=rank)
     blob = synth_weights()
     ctx = _native.Context(local_rank)
-    ctx.load_dscnn(blob, NUM_CLASSES)
+    ct_state = None
+    if args.model == "cnn-trad-fpool3":
+        from oracle import cnn_trad as o_ct  # weight generator + CPU baseline only (test infrastructure)
+
+        ct_state = o_ct.random_state(seed=1)
+        ctx.load_cnn_trad(o_ct.flatten_state(ct_state), NUM_CLASSES)
+        step = lambda: ctx.infer_cnn_trad_i16(wav, logits, labels)
+    else:
+        ctx.load_dscnn(blob, NUM_CLASSES)
+        step = lambda: ctx.infer_i16(wav, logits, labels)
     ctx.reserve(B)
     wav = torch.from_numpy(clips).to(dev)
     logits = torch.empty((B, NUM_CLASSES), dtype=torch.float32, device=dev)
     labels = torch.empty((B,), dtype=torch.int32, device=dev)
 
     for _ in range(args.warmup):
-        ctx.infer_i16(wav, logits, labels)
+        step()
     ctx.sync()
     ctx.prof_enable(True)
     ctx.prof_reset()
@@ -173,13 +240,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    elapsed = timed_steps(lambda: ctx.infer_i16(wav, logits, labels), args.steps, barrier, torch.cuda.synchronize, reduce_max)
+    elapsed = timed_steps(step, args.steps, barrier, torch.cuda.synchronize, reduce_max)
 
     k_ms, k_n = ctx.prof_read(_native.KWS_K_DSCNN)
     m_ms, m_n = ctx.prof_read(_native.KWS_K_MFCC)
     ctx.prof_enable(False)
 
-    if rank == 0:
+    if rank == 0 and args.model == "cnn-trad-fpool3":
+        print(json.dumps(cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, ct_state, logits)), flush=True)
+    elif rank == 0:
         total_clips = B * world * args.steps
         value = total_clips / elapsed
         dscnn_s = (k_ms / max(k_n, 1)) * 1e-3

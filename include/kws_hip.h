@@ -163,6 +163,10 @@ int kws_load_cnn_trad(kws_ctx* ctx, const float* blob, size_t n_floats, int num_
  * convolution output (76 KB per clip) goes through a context workspace that grows on demand. */
 int kws_forward_cnn_trad_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
 
+/* Fused wav -> label for this model (BASELINE.json configs[2]): kws_mfcc_i16 into the context workspace, then
+ * kws_forward_cnn_trad_f32, on the context's stream.  Same arguments and errors as kws_infer_i16. */
+int kws_infer_cnn_trad_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label);
+
 /* ---- posteriors (build-defined: the reference's scripts stop at argmax of the logits,
  * kws/libs/training.py:371) ------------------------------------------------------------------------------ */
 
@@ -212,7 +216,7 @@ int kws_spec512_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int fra
 /* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
  * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
  * launch count per kernel id since the last kws_prof_reset. */
-enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_COUNT = 2 };
+enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_COUNT = 4 };
 int kws_prof_enable(kws_ctx* ctx, int on);
 int kws_prof_reset(kws_ctx* ctx);
 int kws_prof_read(kws_ctx* ctx, int kernel_id, double* total_ms, int* launches);

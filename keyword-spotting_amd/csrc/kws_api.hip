@@ -10,7 +10,8 @@
 
 namespace kws {
 
-const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel"};
+const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel",
+                                               "kws_cnntrad_dense_kernel"};
 
 // ------------------------------------------------------------------------------------------------
 // Host tables (double precision, then rounded once to float32).
@@ -174,9 +175,9 @@ struct kws_ctx {
         hipEvent_t a, b;
     };
     std::vector<EvPair> ev[KWS_K_COUNT];
-    size_t ev_used[KWS_K_COUNT] = {0, 0};
-    double ms_total[KWS_K_COUNT] = {0, 0};
-    long launches[KWS_K_COUNT] = {0, 0};
+    size_t ev_used[KWS_K_COUNT] = {};
+    double ms_total[KWS_K_COUNT] = {};
+    long launches[KWS_K_COUNT] = {};
 };
 
 static thread_local std::string g_create_err;
@@ -763,8 +764,29 @@ int kws_forward_cnn_trad_f32(kws_ctx* c, const float* d_feat, int B, float* d_lo
         c->d_conv_ws = d;
         c->conv_ws_floats = need;
     }
-    HIP_TRY(c, launch_cnntrad(c->stream, c->tw, d_feat, B, c->d_conv_ws, d_logits, d_label));
+    {
+        ProfScope ps(c, KWS_K_CNNTRAD_CONV);
+        HIP_TRY(c, launch_cnntrad_conv(c->stream, c->tw, d_feat, B, c->d_conv_ws));
+    }
+    {
+        ProfScope ps(c, KWS_K_CNNTRAD_DENSE);
+        HIP_TRY(c, launch_cnntrad_dense(c->stream, c->tw, c->d_conv_ws, B, d_logits, d_label));
+    }
     return KWS_OK;
+}
+
+int kws_infer_cnn_trad_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label) {
+    int rc = check_batch(c, d_wav, B, "kws_infer_cnn_trad_i16");
+    if (rc) return rc;
+    if (!c->fe_ready || !c->cnntrad_ready)
+        return fail(c, KWS_ESTATE, "kws_infer_cnn_trad_i16: front end or model not configured (kws_load_cnn_trad)");
+    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
+        return fail(c, KWS_EUNSUPPORTED, "kws_infer_cnn_trad_i16: the kernels are built for a 99 x 10 feature map");
+    rc = kws_reserve(c, B);
+    if (rc) return rc;
+    rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
+    if (rc) return rc;
+    return kws_forward_cnn_trad_f32(c, c->d_feat_ws, B, d_logits, d_label);
 }
 
 int kws_softmax_f32(kws_ctx* c, const float* d_logits, int B, int C, float* d_prob) {

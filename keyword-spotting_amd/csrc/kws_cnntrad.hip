@@ -12,7 +12,7 @@
 // from the zero-padded map in LDS and splits it on the fly; its ReLU'd, frequency-pooled output is written to LDS
 // ALREADY split, as three bf16 planes [position][input channel], so that conv2's B operand -- eight consecutive
 // input channels of one input position -- is a single aligned ds_read_b128 per piece with no VALU work in the
-// loop.  Taps that fall into the padding read a zero row.  conv2's pre-split weights (983 KB) stream from L2.
+// loop.  Taps that fall into the padding read a zero region.  conv2's pre-split weights (983 KB) stream from L2.
 // Kernel B: the dense tail, 32 clips per workgroup; its 19008 -> 32 layer is a GEMM on the same matrix-pipe path.
 #include <type_traits>
 
@@ -26,18 +26,24 @@ constexpr int CT_T = 99, CT_F = 10, CT_FP = 3, CT_P2 = CT_T * CT_FP;  // 297 poo
 constexpr int CT_K1H = 20, CT_K1W = 8, CT_K2H = 10, CT_K2W = 4;
 constexpr int XP_H = CT_T + CT_K1H - 1, XP_W = CT_F + CT_K1W - 1;      // 118 x 17 zero-padded conv1 input
 constexpr int XP_BYTES = 8192;                                          // >= 118*17*4, keeps the planes 16-byte aligned
-constexpr int PL_POS = CT_P2 + 1;                                       // + one all-zero row for padding taps
 constexpr int PL_STRIDE = CH * 2 + 16;                                  // bytes per position: 128 of channels + 16 of padding, so
                                                                         // that the 16 lanes of a ds_read_b128 group (consecutive
                                                                         // positions) fall on 16 different 16-byte bank groups
                                                                         // (at 128 they collide eight ways: measured LDS-bound)
-constexpr int PLANE_BYTES = PL_POS * PL_STRIDE;                         // one bf16 piece plane [pos][64 cin + pad]
-constexpr int CT_LDS_BYTES = XP_BYTES + 3 * PLANE_BYTES;                // 136 928
+// Taps that fall into the padding read zeros.  A single zero row would sit on the banks of one of the valid lanes
+// of the same instruction (two-way conflict on three of four taps: 27 % of conv2's LDS cycles by the counters);
+// instead every plane ends in a 256-byte-aligned zero region and a padding lane reads it at the offset its natural
+// address has modulo 256 -- the bank slot that lane would have used anyway, which no valid lane touches.
+constexpr int PL_ZERO_OFF = (CT_P2 * PL_STRIDE + 255) / 256 * 256;      // 43 008
+constexpr int PL_ZERO_BYTES = 256 + 3 * 32 + 32;                        // natural offset mod 256, + channel block, + read width
+constexpr int PLANE_BYTES = PL_ZERO_OFF + PL_ZERO_BYTES;                // one bf16 piece plane [pos][64 cin + pad] + zero region
+constexpr int CT_LDS_BYTES = XP_BYTES + 3 * PLANE_BYTES;                // 138 368
 constexpr int CT_NW = 8, CT_NT = CT_NW * 64;
 constexpr int C1_TILES = CT_T / 3;                                      // 33 tiles of 3 time rows x 10 bins (30 of 32 columns)
 constexpr int C2_TILES = (CT_P2 + 31) / 32;                             // 10
 static_assert(CT_T % 3 == 0, "conv1 tiles hold whole time rows");
 static_assert(C2_TILES == 10 && CT_NW == 8, "conv2 tile groups {3,3,2,2} x 2 channel tiles assume 10 tiles on 8 wavefronts");
+static_assert(XP_BYTES % 256 == 0 && PL_STRIDE % 16 == 0, "the zero regions rely on 256-byte bank periodicity");
 static_assert(XP_H * XP_W * 4 <= XP_BYTES, "padded input does not fit its LDS slot");
 
 __device__ __forceinline__ float lane_up(float v) { return from_lane_above(v); }
@@ -51,9 +57,10 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
     const int clip = blockIdx.x;
     if (clip >= B) return;
 
-    // ---- stage: zero-padded input map, zero row of the pooled planes ---------------------------------
+    // ---- stage: zero-padded input map, zero regions of the pooled planes ---------------------------------
     for (int i = tid; i < XP_H * XP_W; i += CT_NT) xp[i] = 0.f;
-    if (tid < 3 * CH / 2) reinterpret_cast<uint32_t*>(planes + (tid / (CH / 2)) * PLANE_BYTES + CT_P2 * PL_STRIDE)[tid % (CH / 2)] = 0u;
+    if (tid < 3 * PL_ZERO_BYTES / 4)
+        reinterpret_cast<uint32_t*>(planes + (tid / (PL_ZERO_BYTES / 4)) * PLANE_BYTES + PL_ZERO_OFF)[tid % (PL_ZERO_BYTES / 4)] = 0u;
     __syncthreads();
     for (int i = tid; i < CT_T * CT_F; i += CT_NT)
         xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = feat[(size_t)clip * (CT_T * CT_F) + i];
@@ -148,9 +155,8 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
         for (int i = 0; i < NTILE; ++i) {
             p[i] = (tile0 + i) * 32 + col;
             pvalid[i] = p[i] < CT_P2;
-            const int pc = pvalid[i] ? p[i] : CT_P2 - 1;
-            t[i] = pc / CT_FP;
-            fp[i] = pc % CT_FP;
+            t[i] = p[i] / CT_FP;  // columns past the map keep their natural geometry: they read zeros from their own bank slot
+            fp[i] = p[i] % CT_FP;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         }
@@ -168,8 +174,8 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
             const int kh = kk >> 2, kw = kk & 3;
             const int tin = t[i] + kh - 4, fin = fp[i] + kw - 1;
             const bool ok = pvalid[i] && (unsigned)tin < (unsigned)CT_T && (unsigned)fin < (unsigned)CT_FP;
-            const int pin = ok ? tin * CT_FP + fin : CT_P2;
-            return planes + pin * PL_STRIDE + half * 16;
+            const int natural = (tin * CT_FP + fin) * PL_STRIDE + half * 16;  // may lie outside the plane
+            return planes + (ok ? natural : PL_ZERO_OFF + (natural & 255));
         };
         auto b_load = [&](const unsigned char* const (&ba)[NTILE], int cb, uintx4 (&dst)[NTILE][3]) {
 #pragma unroll
@@ -339,9 +345,13 @@ hipError_t cnntrad_init_device() {
                                CT_LDS_BYTES);
 }
 
-hipError_t launch_cnntrad(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, float* d_logits,
-                          int32_t* d_label) {
+hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws) {
     hipLaunchKernelGGL(kws_cnntrad_conv_kernel, dim3(B), dim3(CT_NT), CT_LDS_BYTES, s, w, d_feat, B, d_conv_ws);
+    return hipGetLastError();
+}
+
+hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const float* d_conv_ws, int B, float* d_logits,
+                                int32_t* d_label) {
     hipLaunchKernelGGL(kws_cnntrad_dense_kernel, dim3((B + 31) / 32), dim3(DN_WAVES * 64), 0, s, w, d_conv_ws, B, d_logits, d_label);
     return hipGetLastError();
 }

@@ -129,8 +129,9 @@ struct CnnTradWeights {
     int num_classes;
 };
 hipError_t cnntrad_init_device();
-hipError_t launch_cnntrad(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, float* d_logits,
-                          int32_t* d_label);
+hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws);
+hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const float* d_conv_ws, int B, float* d_logits,
+                                int32_t* d_label);
 
 hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,

@@ -19,7 +19,7 @@ from kws.common.errors import AudioProcessingError, KWSError, ModelError
 LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-KWS_K_MFCC, KWS_K_DSCNN = 0, 1
+KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE = 0, 1, 2, 3
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
 PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16 (default): exact three-way bf16 split, six bf16 MFMAs per f32 product
@@ -52,6 +52,7 @@ SIGNATURES = {
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
     "kws_load_cnn_trad": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
     "kws_forward_cnn_trad_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
+    "kws_infer_cnn_trad_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_softmax_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p]),
     "kws_stream_smooth_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p, _i32p]),
     "kws_augment_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, C.c_void_p, _f32p, C.c_int, C.c_void_p, _f32p, C.c_void_p, _f32p]),
@@ -185,6 +186,10 @@ class Context:
     def forward_cnn_trad_f32(self, feat, logits, label=None):
         self._check(self._lib.kws_forward_cnn_trad_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits),
                                                        _ptr(label) if label is not None else None), ModelError)
+
+    def infer_cnn_trad_i16(self, wav, logits, label=None):
+        self._check(self._lib.kws_infer_cnn_trad_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits),
+                                                     _ptr(label) if label is not None else None), ModelError)
 
     def softmax_f32(self, logits, prob):
         self._check(self._lib.kws_softmax_f32(self._h, _ptr(logits), int(logits.shape[0]), int(logits.shape[1]), _ptr(prob)),

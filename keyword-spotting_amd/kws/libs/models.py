@@ -243,3 +243,17 @@ class CnnTradFpool3(KeywordSpottingModel):
         labels = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
         ctx.forward_cnn_trad_f32(x, logits, labels)
         return (logits, labels) if return_labels else logits
+
+    def infer_pcm16(self, wav: torch.Tensor):
+        """Fused path (BASELINE.json configs[2]): ``int16[B,16000]`` PCM on the GPU -> (logits, labels); MFCC +
+        cnn-trad-fpool3 back to back on one stream (``kws_infer_cnn_trad_i16``)."""
+        if not wav.is_cuda:
+            raise ModelError("CnnTradFpool3.infer_pcm16 needs a CUDA/ROCm tensor: the path is HIP kernels and has no CPU fallback")
+        if wav.dtype != torch.int16 or wav.dim() != 2:
+            raise ModelError("infer_pcm16 expects an int16 tensor [B, n_samples]")
+        ctx = self._context(wav.device.index or 0)
+        wav = wav.contiguous()
+        logits = torch.empty((wav.shape[0], self.num_classes), dtype=torch.float32, device=wav.device)
+        labels = torch.empty((wav.shape[0],), dtype=torch.int32, device=wav.device)
+        ctx.infer_cnn_trad_i16(wav, logits, labels)
+        return logits, labels

@@ -626,3 +626,35 @@ def test_cnn_trad_fpool3_matches_its_cpu_definition(dev):
     clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL * scale).numpy()
     assert np.array_equal(labels.cpu().numpy()[clear], want.argmax(dim=1).numpy()[clear])
     assert clear.mean() > 0.8
+
+
+def test_cnn_trad_fpool3_fused_wav_to_label(dev):
+    """BASELINE configs[2] (MFCC + cnn-trad-fpool3 fused): int16 PCM through kws_infer_cnn_trad_i16 vs the oracle's
+    MFCC followed by the model's CPU definition; the two-call path (kws_mfcc_i16, kws_forward_cnn_trad_f32) gives
+    the same bits; a context without the model refuses the call."""
+    from kws.common.errors import ModelError
+    from kws.libs.models import CnnTradFpool3
+    from oracle import cnn_trad as o_ct
+
+    state = o_ct.random_state(seed=5)
+    m = CnnTradFpool3(12)
+    m.load_state_dict(state)
+    clips = synth_clips(40, 3, "gauss")
+    want = o_ct.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips)))
+    wav = torch.from_numpy(clips).to(dev)
+    logits, labels = m.infer_pcm16(wav)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((logits.cpu() - want).abs().max())
+    assert err <= TOL * scale, (err, scale)
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL * scale).numpy()
+    assert np.array_equal(labels.cpu().numpy()[clear], want.argmax(dim=1).numpy()[clear])
+    assert clear.mean() > 0.8
+    ctx = m._context(0)
+    feat = torch.empty((40, 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(wav, feat)
+    two_call = m.forward(feat)
+    torch.cuda.synchronize()
+    assert torch.equal(two_call, logits)
+    with pytest.raises(ModelError):
+        m.infer_pcm16(wav.cpu())
