@@ -1,11 +1,12 @@
 // Micro-benchmark (diagnostics): bf16 MFMA (32x32x16) issue rate, and how much VALU a co-resident wave still gets.
+#pragma clang diagnostic ignored "-Wunused-value"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE>  // 0: MFMA waves only, 1: VALU waves only, 2: both
+template <int MODE, int OP>  // MODE 0: MFMA waves only, 1: VALU waves only, 2: both; OP 0: v_fma_f32, 1: v_dot2_f32_bf16, 2: v_cvt_pk_bf16_f32
 __global__ void k(float* out, unsigned long long* cyc, int iters) {
     const int wave = threadIdx.x >> 6;
     const bool mfma_wave = wave < 4;
@@ -32,7 +33,11 @@ __global__ void k(float* out, unsigned long long* cyc, int iters) {
 #pragma unroll
                 for (int u = 0; u < 64; ++u) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) f[i] = fmaf(f[i], b, a);
+                    for (int i = 0; i < 8; ++i) {
+                        if (OP == 0) f[i] = fmaf(f[i], b, a);
+                        if (OP == 1) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(f[i]) : "v"(b), "s"(0x0000BF80u));
+                        if (OP == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+                    }
                 }
             }
     }
@@ -44,27 +49,31 @@ __global__ void k(float* out, unsigned long long* cyc, int iters) {
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int MODE>
+template <int MODE, int OP>
 void run(const char* name) {
     const int grid = 256, iters = 64;
     float* out; unsigned long long* cyc;
     hipMalloc(&out, sizeof(float) * grid * 512);
     hipMalloc(&cyc, sizeof(unsigned long long) * grid * 8);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(512), 0, 0, out, cyc, iters);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE, OP>), dim3(grid), dim3(512), 0, 0, out, cyc, iters);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(grid * 8);
     hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
     double m = 0, v = 0;
     for (int g = 0; g < grid; ++g) for (int w = 0; w < 8; ++w) (w < 4 ? m : v) += h[g * 8 + w];
     m /= grid * 4; v /= grid * 4;
-    printf("%-28s MFMA waves: %8.0f cycles (%.1f per MFMA)   VALU waves: %8.0f cycles (%.2f per v_fma)\n", name, m,
+    printf("%-28s MFMA waves: %8.0f cycles (%.1f per MFMA)   VALU waves: %8.0f cycles (%.2f per VALU op)\n", name, m,
            m / (iters * 32.0), v, v / (iters * 64.0 * 8));
     hipFree(out); hipFree(cyc);
 }
 
 int main() {
-    run<0>("bf16 32x32x16 MFMA alone");
-    run<1>("VALU waves alone");
-    run<2>("bf16 MFMA + VALU, same SIMDs");
+    run<0, 0>("bf16 32x32x16 MFMA alone");
+    run<1, 0>("v_fma_f32 waves alone");
+    run<2, 0>("bf16 MFMA + v_fma_f32");
+    run<1, 1>("v_dot2_f32_bf16 waves alone");
+    run<2, 1>("bf16 MFMA + v_dot2_f32_bf16");
+    run<1, 2>("v_cvt_pk_bf16_f32 alone");
+    run<2, 2>("bf16 MFMA + v_cvt_pk_bf16");
     return 0;
 }
