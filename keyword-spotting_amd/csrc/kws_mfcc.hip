@@ -74,6 +74,7 @@ constexpr int XROW = 72;
 
 // Per-wavefront LDS scratch (bytes): exchange / spectrum / power buffer, log-mel vectors.
 constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_LBUF = 4608, SCR_BYTES = 4608 + 512;
+static_assert(KWS_MFCC_WAVES * SCR_BYTES >= NFFT * 4, "frame loads may run up to NFFT floats past the staged span, into the scratch");
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 // LDS byte address of a pointer into shared memory (for hand-written ds_* instructions)
@@ -471,19 +472,24 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         const float* ya = ybuf + (2 * pr) * p.frame_step;
         const float* yb = ya + p.frame_step;
 
+        // The loads are unconditional and the frame bound is applied by a select: a read past the frame (at most
+        // 511 floats past the staged span) lands in the wavefronts' scratch behind ybuf -- allocated LDS, any bits --
+        // and is discarded; conditional loads compile to one branch per load.  The all-zero test ORs the bit
+        // patterns (sign bit dropped: -0.0 counts as zero, like the float comparison).
         cf v[8];
-        bool nza = false, nzb = false;
+        uint32_t ora = 0u, orb = 0u;
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) {
             const int i = 64 * n1 + lane;
             const bool in = i < p.frame_len;
-            v[n1].x = in ? ya[i] : 0.f;
-            v[n1].y = (in && has_b) ? yb[i] : 0.f;
-            nza |= v[n1].x != 0.f;
-            nzb |= v[n1].y != 0.f;
+            const float a = ya[i], b = yb[i];
+            v[n1].x = in ? a : 0.f;
+            v[n1].y = (in && has_b) ? b : 0.f;
+            ora |= __builtin_bit_cast(uint32_t, v[n1].x);
+            orb |= __builtin_bit_cast(uint32_t, v[n1].y);
         }
-        nza = __any(nza);
-        nzb = __any(nzb);
+        const bool nza = __any((ora << 1) != 0u);
+        const bool nzb = __any((orb << 1) != 0u);
         mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
                   out + ((size_t)clip * p.num_frames + fa) * p.numcep,
                   out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);

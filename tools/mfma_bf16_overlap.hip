@@ -37,6 +37,18 @@ __global__ void k(float* out, unsigned long long* cyc, int iters) {
                         if (OP == 0) f[i] = fmaf(f[i], b, a);
                         if (OP == 1) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(f[i]) : "v"(b), "s"(0x0000BF80u));
                         if (OP == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+                        if (OP == 3) asm volatile("v_and_b32 %0, %1, %0" : "+v"(f[i]) : "s"(0xffff0000u));
+                        if (OP == 4) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(b), "s"(0x07060302u));
+                        if (OP == 5) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+                        if (OP == 6) asm volatile("v_fmac_f32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(f[i]) : "v"(b));
+                        if (OP == 7) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+                        if (OP == 8) asm volatile("v_max_f32 %0, 0, %0" : "+v"(f[i]));
+                        if (OP == 9) asm volatile("v_add_u32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
+                        if (OP == 10) asm volatile("v_mov_b32 %0, %1" : "+v"(f[i]) : "v"(b));
+                        if (OP == 11) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(b), "v"(a));
+                        if (OP == 12) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(f[i]) : "s"(0xffff0000u), "v"(b));
+                        if (OP == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(b));
+                        if (OP == 14) asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
                     }
                 }
             }
@@ -75,5 +87,20 @@ int main() {
     run<2, 1>("bf16 MFMA + v_dot2_f32_bf16");
     run<1, 2>("v_cvt_pk_bf16_f32 alone");
     run<2, 2>("bf16 MFMA + v_cvt_pk_bf16");
+    run<1, 3>("v_and_b32 alone");
+    run<1, 4>("v_perm_b32 alone");
+    run<1, 5>("v_sub_f32 alone");
+    run<1, 6>("v_fmac_f32_dpp alone");
+    run<1, 7>("v_mul_f32 alone");
+    run<1, 8>("v_max_f32 alone");
+    run<1, 9>("v_add_u32 alone");
+    run<1, 10>("v_mov_b32 alone");
+    run<1, 11>("v_fma_f32 (asm) alone");
+    run<1, 12>("v_and_or_b32 alone");
+    run<1, 13>("v_cndmask_b32 alone");
+    run<1, 14>("v_exp_f32 alone");
+    run<2, 3>("bf16 MFMA + v_and_b32");
+    run<2, 4>("bf16 MFMA + v_perm_b32");
+    run<2, 6>("bf16 MFMA + v_fmac_dpp");
     return 0;
 }
