@@ -230,6 +230,11 @@ int kws_host_mel_edges(int nfilt, int nfft, int sample_rate, int* edges_out);
 /* Dense float32 [nfilt, nfft/2+1] filterbank expanded from the sparse per-lane tables the kernel
  * uses (so the sparse decomposition can be checked against the oracle's dense matrix on CPU). */
 int kws_host_mel_dense(int nfilt, int nfft, int sample_rate, float* fb_out);
+/* Lane layout of the sparse mel evaluation: for each of the nfilt+1 inter-edge segments the first lane and the number
+ * of lanes (chunks of 8 bins) it occupies; *lanes_used = lanes in use including idle padding; *row_safe = 1 when no
+ * segment straddles a 16-lane DPP row (the kernel then shifts with row_shl operands).  first_lane_out / n_lanes_out
+ * hold nfilt+1 ints; lanes_used / row_safe may be NULL. */
+int kws_host_mel_layout(int nfilt, int nfft, int sample_rate, int* first_lane_out, int* n_lanes_out, int* lanes_used, int* row_safe);
 /* float32 [numcep, nfilt] DCT-II(ortho) x lifter table the kernel uses. */
 int kws_host_dct_lifter(int nfilt, int numcep, int ceplifter, float* out);
 

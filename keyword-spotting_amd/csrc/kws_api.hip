@@ -52,26 +52,46 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
     out.gather.assign(64, 0u);
     out.slot.assign(nfft / 2, 0);
     std::vector<int> seg_first(nfilt + 2, 0), seg_count(nfilt + 2, 0);
-    int nchunks = 0;
-    // segment s = bins [edge_s, edge_s+1): rising side of filter s (s < nfilt), falling side of filter s-1 (s >= 1)
+    // segment s = bins [edge_s, edge_s+1): rising side of filter s (s < nfilt), falling side of filter s-1 (s >= 1);
+    // it is cut into chunks of MEL_CHUNK bins, one chunk per lane, the chunks of a segment on adjacent lanes.
+    int dense_lanes = 0;
     for (int s = 0; s <= nfilt; ++s) {
-        const int lo = out.edges[s], hi = out.edges[s + 1];
-        seg_first[s] = nchunks;
-        for (int k0 = lo; k0 < hi; k0 += MEL_CHUNK) {
-            if (nchunks >= 64) {
-                err = "mel filterbank needs more than 64 chunks of 8 bins";
+        seg_count[s] = (out.edges[s + 1] - out.edges[s] + MEL_CHUNK - 1) / MEL_CHUNK;
+        dense_lanes += seg_count[s];
+    }
+    if (dense_lanes > 64) {
+        err = "mel filterbank needs more than 64 chunks of 8 bins";
+        return false;
+    }
+    // Lane layout: no segment straddles a 16-lane DPP row (idle lanes pad the rows), so the segmented sums can shift
+    // with row_shl:1/2/4 fused into v_fmac_f32_dpp.  Every filterbank that fits 64 dense chunks at nfft = 512 and
+    // the sample rates tried also fits this way (many filters = short segments); one that does not is refused.
+    {
+        int cursor = 0;
+        for (int s = 0; s <= nfilt; ++s) {
+            if (cursor % 16 + seg_count[s] > 16) cursor = (cursor + 15) / 16 * 16;
+            seg_first[s] = cursor;
+            cursor += seg_count[s];
+            if (seg_count[s] > 8 || cursor > 64) {
+                err = "mel filterbank does not fit 64 lanes with every segment (<= 8 chunks) inside one 16-lane row";
                 return false;
             }
-            out.k0[nchunks] = k0;
-            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) out.slot[k0 + i] = MEL_CHUNK * nchunks + i;
+        }
+    }
+    int nchunks = 0;  // lanes in use (idle padding lanes included)
+    for (int s = 0; s <= nfilt; ++s) {
+        const int lo = out.edges[s], hi = out.edges[s + 1];
+        int c = seg_first[s];
+        for (int k0 = lo; k0 < hi; k0 += MEL_CHUNK, ++c) {
+            out.k0[c] = k0;
+            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) out.slot[k0 + i] = MEL_CHUNK * c + i;
             for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) {
                 const double k = k0 + i, width = (double)(hi - lo);
-                if (s < nfilt) out.rw[i * 64 + nchunks] = (float)((k - lo) / width);
-                if (s >= 1) out.fw[i * 64 + nchunks] = (float)((hi - k) / width);
+                if (s < nfilt) out.rw[i * 64 + c] = (float)((k - lo) / width);
+                if (s >= 1) out.fw[i * 64 + c] = (float)((hi - k) / width);
             }
-            ++nchunks;
         }
-        seg_count[s] = nchunks - seg_first[s];
+        nchunks = std::max(nchunks, c);
     }
     // which neighbours (chunk + 1, + 2, + 4) share a chunk's segment: drives the in-register segmented sums
     out.seg.assign(64, 0);
@@ -86,8 +106,7 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
             for (int d = 0; d < 3; ++d)
                 if (i + (1 << d) < seg_count[s]) out.seg[seg_first[s] + i] |= 1 << d;
     }
-    if (deep)
-        for (int c = 0; c < 64; ++c) out.seg[c] |= 128;
+    for (int c = 0; c < 64; ++c) out.seg[c] |= (deep ? 128 : 0) | 64;  // bit 6: row-safe layout (always)
     for (int j = 0; j < nfilt; ++j) {
         if (seg_count[j] > 255 || seg_count[j + 1] > 255) {
             err = "mel segment too long";
@@ -1016,6 +1035,23 @@ int kws_host_mel_dense(int nfilt, int nfft, int sample_rate, float* fb_out) {
                 if (k < nb) fb_out[(size_t)j * nb + k] += mel.fw[i * 64 + c];
             }
     }
+    return KWS_OK;
+}
+
+int kws_host_mel_layout(int nfilt, int nfft, int sample_rate, int* first_lane_out, int* n_lanes_out, int* lanes_used, int* row_safe) {
+    if (!first_lane_out || !n_lanes_out) return KWS_EINVAL;
+    MelHost mel;
+    std::string err;
+    if (!build_mel_host(nfilt, nfft, sample_rate, mel, err)) return KWS_EUNSUPPORTED;
+    // segment s = filter s's rising side; the last segment is the falling side of the last filter
+    for (int j = 0; j < nfilt; ++j) {
+        first_lane_out[j] = (int)(mel.gather[j] & 255);
+        n_lanes_out[j] = (int)((mel.gather[j] >> 8) & 255);
+    }
+    first_lane_out[nfilt] = (int)((mel.gather[nfilt - 1] >> 16) & 255);
+    n_lanes_out[nfilt] = (int)(mel.gather[nfilt - 1] >> 24);
+    if (lanes_used) *lanes_used = mel.n_chunks;
+    if (row_safe) *row_safe = (mel.seg[0] & 64) ? 1 : 0;
     return KWS_OK;
 }
 

@@ -49,7 +49,7 @@ struct FrontendTables {
     const float* mel_fw;       // [8][64]    falling-edge weights
     const uint32_t* mel_gather;// [64]       per filter: r0 | nr<<8 | f0<<16 | nf<<24  (chunk ranges)
     const int* mel_slot;       // [256]      power-buffer slot of bin k = 8*chunk(k) + (k - first bin of the chunk)
-    const int* mel_seg;        // [64]       per chunk: bit d (0..2) = chunk + 2^d is in the same segment; bit 7 = deep
+    const int* mel_seg;        // [64]       per chunk: bit d (0..2) = chunk + 2^d is in the same segment; bit 6 = no segment straddles a 16-lane row; bit 7 = deep
     const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
 };
 

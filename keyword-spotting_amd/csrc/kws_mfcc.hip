@@ -283,17 +283,43 @@ __device__ __forceinline__ void load_mel_lane(const FrontendTables& t, int lane,
     m.deep = __any((seg & 128) != 0);
 }
 
-// lane c <- lane c+1 across the wavefront (0 shifted in at the top)
-__device__ __forceinline__ float lane_above(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+// A wavefront's scratch starts out as whatever the previous kernel left in LDS.  Power-buffer slots past a chunk's
+// length (and the chunks of idle lanes) are never written but are read and multiplied by zero weights, so they must
+// hold finite values: clear the scratch once per workgroup.
+__device__ __forceinline__ void zero_scratch(unsigned char* scr, int lane) {
+    static_assert(SCR_BYTES % (64 * 16) == 0, "one 16-byte store per lane and round");
+#pragma unroll
+    for (int i = 0; i < SCR_BYTES / (64 * 16); ++i)
+        reinterpret_cast<float4*>(scr)[i * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
-// Sum of v over the chunks lane, lane+1, ... that belong to the same segment (suffix sum by doubling: after the
-// steps the FIRST chunk of every segment holds the segment total).  Segments of up to 8 chunks.
-__device__ __forceinline__ float segment_suffix_sum(float v, const MelLane& m) {
-    v = fmaf(m.m1, lane_above(v), v);
-    v = fmaf(m.m2, lane_above(lane_above(v)), v);
-    if (m.deep) v = fmaf(m.m4, lane_above(lane_above(lane_above(lane_above(v)))), v);
-    return v;
+
+// Sums of v over the chunks lane, lane+1, ... that belong to the same segment (suffix sum by doubling: after the
+// steps the FIRST chunk of every segment holds the segment total), for the four accumulators of a frame pair.
+// Segments of up to 8 chunks; the host keeps every segment inside one 16-lane DPP row, so the shifts by 1, 2 and 4
+// lanes are row_shl operands of the multiply-add itself: three instructions per sum (shifting across the whole
+// wavefront takes 1 + 2 + 4 wave_shl:1 moves on top).
+__device__ __forceinline__ void segment_suffix_sums(float& a, float& b, float& c, float& d, const MelLane& m) {
+    // four independent chains interleaved: three other instructions sit between a write and its DPP read (the VALU ->
+    // DPP hazard needs two wait states; inline asm hides it from the compiler, hence the leading s_nop)
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %0, %0, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %1, %1, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %2, %2, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %3, %5 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+        : "v"(m.m1), "v"(m.m2));
+    if (m.deep)
+        asm("s_nop 1\n\t"
+            "v_fmac_f32_dpp %0, %0, %4 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %1, %1, %4 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %2, %2, %4 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %3, %3, %4 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d)
+            : "v"(m.m4));
 }
 
 // One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
@@ -337,10 +363,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     // Filter j = rising sum over segment j + falling sum over segment j+1.  The chunks of a segment are adjacent
     // lanes: a suffix sum by doubling (DPP shifts, no LDS) leaves each segment's total in its first chunk, and lane
     // j fetches its two totals through the LDS crossbar (ds_bpermute: no memory, no bank conflicts).
-    ra = segment_suffix_sum(ra, ml);
-    fa_ = segment_suffix_sum(fa_, ml);
-    rb = segment_suffix_sum(rb, ml);
-    fb_ = segment_suffix_sum(fb_, ml);
+    segment_suffix_sums(ra, fa_, rb, fb_, ml);
     float la = 0.f, lb = 0.f;
     {
         const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
@@ -458,9 +481,10 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     load_twiddles(t.twiddle, lane, t1);
     MelLane ml;
     load_mel_lane(t, lane, ml);
+    unsigned char* scr = scr0 + wv * SCR_BYTES;
+    zero_scratch(scr, lane);
     __syncthreads();  // the only workgroup barrier: staged samples and tables are visible to all waves
 
-    unsigned char* scr = scr0 + wv * SCR_BYTES;
     const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
                             reinterpret_cast<float*>(scr + SCR_LBUF),
                             dctb, tw2, nfp};
@@ -599,6 +623,7 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
         dctb[i] = j < p.nfilt ? t.dct[r * p.nfilt + j] : 0.f;
     }
     fill_tw2(t.twiddle, tw2, lane);
+    zero_scratch(scr, lane);
     cf t1[8];
     load_twiddles(t.twiddle, lane, t1);
     MelLane ml;

@@ -66,6 +66,8 @@ SIGNATURES = {
     "kws_kernel_name": (C.c_char_p, [C.c_int]),
     "kws_host_mel_edges": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "kws_host_mel_dense": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "kws_host_mel_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
     "kws_host_dct_lifter": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 
@@ -303,6 +305,17 @@ def host_mel_dense(nfilt=26, nfft=512, sample_rate=16000) -> np.ndarray:
     if rc != KWS_OK:
         raise KWSError(f"kws_host_mel_dense failed ({rc})")
     return out
+
+
+def host_mel_layout(nfilt=26, nfft=512, sample_rate=16000):
+    """(first_lane[nfilt+1], n_lanes[nfilt+1], lanes_used, row_safe) of the sparse mel evaluation."""
+    first = (C.c_int * (nfilt + 1))()
+    count = (C.c_int * (nfilt + 1))()
+    used, safe = C.c_int(0), C.c_int(0)
+    rc = lib().kws_host_mel_layout(nfilt, nfft, sample_rate, first, count, C.byref(used), C.byref(safe))
+    if rc != KWS_OK:
+        raise KWSError(f"kws_host_mel_layout failed ({rc})")
+    return np.array(first[:], dtype=np.int64), np.array(count[:], dtype=np.int64), int(used.value), bool(safe.value)
 
 
 def host_dct_lifter(nfilt=26, numcep=10, ceplifter=22) -> np.ndarray:

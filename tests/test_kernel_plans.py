@@ -98,6 +98,24 @@ def test_host_mel_tables_match_oracle(nfilt, sr):
     assert np.array_equal(fb != 0, ref != 0)  # identical sparsity: 459 non-zeros for the default
 
 
+@pytest.mark.parametrize("nfilt,sr", [(26, 16000), (40, 16000), (20, 8000), (13, 22050), (26, 44100), (54, 16000)])
+def test_host_mel_lane_layout(nfilt, sr):
+    """Segments sit on adjacent lanes, in order, without overlap, inside the wavefront, and none of them straddles a
+    16-lane DPP row (the kernel's segmented sums shift with row_shl); a filterbank that cannot be laid out so is refused."""
+    first, count, used, row_safe = native.host_mel_layout(nfilt, 512, sr)
+    edges = native.host_mel_edges(nfilt, 512, sr)
+    assert count.tolist() == [-(-int(edges[s + 1] - edges[s]) // 8) for s in range(nfilt + 1)]
+    end = 0
+    for f, c in zip(first, count):
+        assert f >= end  # in order, no overlap (idle lanes may pad)
+        end = f + c
+        if c:
+            assert f // 16 == (f + c - 1) // 16
+    assert row_safe and end <= used <= 64
+    with pytest.raises(Exception):
+        native.host_mel_layout(64, 512, 16000)  # 65 segments do not fit 64 lanes
+
+
 @pytest.mark.parametrize("nfilt,numcep,L", [(26, 10, 22), (26, 13, 22), (40, 12, 0)])
 def test_host_dct_lifter_matches_oracle(nfilt, numcep, L):
     want = o.dct2_ortho_matrix(nfilt, numcep) * o.lifter_vector(numcep, L)[:, None]
