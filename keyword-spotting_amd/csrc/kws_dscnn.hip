@@ -239,73 +239,117 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 // conv1 on the bf16 matrix pipe (split path).  K order: the half-wave h takes kernel rows 5h..5h+4, so both
 // halves walk the same 56 offsets f = 8kb + j -> (kh%5 = f/10, kw = f%10) (f >= 50: zero weights) and lane
 // (col, h) of k-block kb supplies im2col values feat[2oh + 5h + f/10][2ow + f%10], j = 0..7, split into three bf16
-// pieces like the pointwise operands.  c1f: this wave's channel tile, [kb][piece], loaded at kernel start.
-__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3]) {
-    const float* featp = lds + OFF_FEAT;
-    float* z0 = lds + OFF_Z0;
-    const int lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
-    const int ct = wv & 1;  // units u = wv, wv + NW share the output-channel tile (NW is even)
-    for (int u = wv; u < 10; u += NW) {
-        const int pos = (u >> 1) * 32 + col;
-        const int posc = pos < P0 ? pos : P0 - 1;
-        const int oh = posc / C1_W, ow = posc % C1_W;
-        const float* base = featp + (2 * oh + 5 * half) * FEAT_W + 2 * ow;
-        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;  // two chains keep the matrix pipe fed
-        float y[2][8];
-        auto gather = [&](int kb, float (&dst)[8]) {  // offsets f, f+1 (f even) are neighbours in one row: 8-byte reads
+// pieces like the pointwise operands.  c1f: the channel tile wv & 1, [kb][piece], loaded at kernel start.
+//
+// Work split: 141 positions = 5 tiles of 32, two channel tiles each.  As ten (tile, channel tile) units on eight
+// wavefronts two wavefronts run two units back to back and every unit gathers and splits its tile's im2col values
+// again.  Instead wavefronts 0-3 take tiles 0-3 for BOTH channel tiles (one gather + split feeds twelve MFMAs per
+// k-block; the other tile's A fragments stream from L2 through a two-deep ring), wavefronts 4 and 5 take tile 4 for
+// one channel tile each, 6 and 7 have no conv1 work: one round, and the busiest SIMD (a dual and a single unit)
+// carries the matrix work of three single units but two split streams instead of three.
+template <bool DUAL>
+__device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const float* featp, float* z0, int ptile, int ct, int lane,
+                                                 const uintx4 (&c1f)[7][3]) {
+    const int half = lane >> 5, col = lane & 31;
+    const int pos = ptile * 32 + col;
+    const int posc = pos < P0 ? pos : P0 - 1;
+    const int oh = posc / C1_W, ow = posc % C1_W;
+    const float* base = featp + (2 * oh + 5 * half) * FEAT_W + 2 * ow;
+    const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 acc = zero, acc2 = zero;  // two chains per channel tile keep the matrix pipe fed
+    floatx16 occ = zero, occ2 = zero;  // the other channel tile (DUAL)
+    const uintx4* osrc = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(ct ^ 1) * (7 * 3 * 64) + lane;
+    uintx4 of[2][3];                   // its A fragments: k-block kb in of[kb & 1], requested two k-blocks ahead
+    auto load_other = [&](int kb) {
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const float2 v = *reinterpret_cast<const float2*>(base + ((8 * kb + j) / 10) * FEAT_W + (8 * kb + j) % 10);
-                dst[j] = v.x;
-                dst[j + 1] = v.y;
+        for (int pc = 0; pc < 3; ++pc) of[kb & 1][pc] = osrc[(kb * 3 + pc) * 64];
+    };
+    if (DUAL) {
+        load_other(0);
+        load_other(1);
+    }
+    float y[2][8];
+    auto gather = [&](int kb, float (&dst)[8]) {  // offsets f, f+1 (f even) are neighbours in one row: 8-byte reads
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const float2 v = *reinterpret_cast<const float2*>(base + ((8 * kb + j) / 10) * FEAT_W + (8 * kb + j) % 10);
+            dst[j] = v.x;
+            dst[j + 1] = v.y;
+        }
+    };
+    uintx4 bf[2][3];  // [buffer][hi, mid, lo] B operands: k-block kb multiplies while kb+1 is being split
+    gather(0, y[0]);
+    gather(1, y[1]);
+    split3(y[0], bf[0][0], bf[0][1], bf[0][2]);
+    gather(2, y[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+        const int cur = kb & 1, nxt = cur ^ 1;
+        // the six products of this k-block (per channel tile), smallest first, spread over the next k-block's split
+        auto product = [&](int q) {
+            const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+            const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
+            if (q & 1)
+                acc2 = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc2);
+            else
+                acc = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DUAL) {
+                if (q & 1)
+                    occ2 = mfma_bf16(of[cur][pa], bf[cur][pb], occ2);
+                else
+                    occ = mfma_bf16(of[cur][pa], bf[cur][pb], occ);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        uintx4 bf[2][3];  // [buffer][hi, mid, lo] B operands: k-block kb multiplies while kb+1 is being split
-        gather(0, y[0]);
-        gather(1, y[1]);
-        split3(y[0], bf[0][0], bf[0][1], bf[0][2]);
-        gather(2, y[0]);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = 0; kb < 7; ++kb) {
-            const int cur = kb & 1, nxt = cur ^ 1;
-            // the six products of this k-block, smallest first, one per quarter of the next k-block's split
-            auto product = [&](int q) {
-                const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-                const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
-                if (q & 1)
-                    acc2 = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc2);
-                else
-                    acc = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc);
+        for (int i = 0; i < 4; ++i) {
+            product(i);
+            if (kb + 1 < 7) {
+                const float a0 = y[nxt][2 * i], a1 = y[nxt][2 * i + 1];
+                const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
+                bf[nxt][0][i] = pack_top16(a0, a1);
+                bf[nxt][1][i] = pack_top16(r0, r1);
+                bf[nxt][2][i] = pack_top16(r0 - top16(r0), r1 - top16(r1));
                 __builtin_amdgcn_sched_barrier(0);
-            };
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                product(i);
-                if (kb + 1 < 7) {
-                    const float a0 = y[nxt][2 * i], a1 = y[nxt][2 * i + 1];
-                    const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
-                    bf[nxt][0][i] = pack_top16(a0, a1);
-                    bf[nxt][1][i] = pack_top16(r0, r1);
-                    bf[nxt][2][i] = pack_top16(r0 - top16(r0), r1 - top16(r1));
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
-            product(4);
-            if (kb + 3 < 7) gather(kb + 3, y[nxt]);
-            __builtin_amdgcn_sched_barrier(0);
-            product(5);
         }
-        acc += acc2;
-        if (pos < P0) {
+        product(4);
+        if (kb + 3 < 7) gather(kb + 3, y[nxt]);
+        __builtin_amdgcn_sched_barrier(0);
+        product(5);
+        if (DUAL && kb + 2 < 7) {
+            load_other(kb + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    acc += acc2;
+    occ += occ2;
+    if (pos < P0) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
-                const int co = ct * 32 + row_of(r, half);
-                *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) =
-                    make_float2(relu(acc[r] + w.c1_b[co]), relu(acc[r + 1] + w.c1_b[co + 1]));
+        for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
+            const int co = ct * 32 + row_of(r, half);
+            *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) =
+                make_float2(relu(acc[r] + w.c1_b[co]), relu(acc[r + 1] + w.c1_b[co + 1]));
+            if (DUAL) {
+                const int oo = (ct ^ 1) * 32 + row_of(r, half);
+                *reinterpret_cast<float2*>(z0 + pidx(oo, pos, P0 + 2)) =
+                    make_float2(relu(occ[r] + w.c1_b[oo]), relu(occ[r + 1] + w.c1_b[oo + 1]));
             }
         }
     }
+}
+
+__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3]) {
+    static_assert(P0 > 4 * 32 && P0 <= 5 * 32 && NW >= 6, "conv1 work split: four dual tiles + one tile in two halves");
+    const float* featp = lds + OFF_FEAT;
+    float* z0 = lds + OFF_Z0;
+    const int lane = tid & 63, wv = tid >> 6;
+    if (wv < 4)
+        conv1_unit_split<true>(w, featp, z0, wv, wv & 1, lane, c1f);
+    else if (wv < 6)
+        conv1_unit_split<false>(w, featp, z0, 4, wv & 1, lane, c1f);
     if (tid < CH) {  // extra slots of the conv1 planes: no ring in block 1, slot P+1 is the zero pad
         z0[pidx(tid, P0, P0 + 2)] = 0.f;
         z0[pidx(tid, P0 + 1, P0 + 2)] = 0.f;
