@@ -27,43 +27,61 @@
 namespace kws {
 namespace {
 
-// 8-byte aligned so the compiler moves a complex value with one ds_read_b64 / ds_write_b64 (an unaligned
-// pair becomes ds_read2_b32: twice the LDS cycles and the 32-bank conflict rules)
-struct alignas(8) cf {
-    float x, y;
-};
+// 8-byte aligned, so a complex value moves with one ds_read_b64 / ds_write_b64 (an unaligned pair becomes
+// ds_read2_b32: twice the LDS cycles and the 32-bank conflict rules).
+// A 2-vector, so a complex value lives in an aligned register pair: the compiler then maps complex adds, the
+// rotations by -i / (1 -+ i)/sqrt2 and the twiddle products onto packed instructions (v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32 with op_sel / neg modifiers for the swaps and signs) without moves to build the pairs; with a scalar
+// struct the vectoriser paired components of different values and a sixth of the kernel's VALU instructions were
+// v_mov_b32.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+// (fma(a.x, b.x, -(a.y*b.y)), fma(a.x, b.y, a.y*b.x)) in two packed instructions: the component swaps are op_sel
+// operands (op_sel picks the source half of the low lane, op_sel_hi of the high lane) and the one-sided negation is
+// neg_lo -- the compiler only folds whole-vector negations and builds (-b.y, b.x) with an xor and a move instead.
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    return {fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (-a.y*b.y, a.y*b.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));            // a.x*(b.x, b.y) + t
+    return r;
 }
-// multiply by -i
-__device__ __forceinline__ cf mul_mi(cf a) { return {a.y, -a.x}; }
+// a + (-i) b = (a.x + b.y, a.y - b.x) and a - (-i) b = (a.x - b.y, a.y + b.x): the rotation by -i is the operand
+// swap, one packed instruction each (same reason as cmul)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // In-place 8-point forward DFT, natural order in and out: v[k] = sum_n v[n] * exp(-2*pi*i*n*k/8).
 __device__ __forceinline__ void dft8(cf (&v)[8]) {
     constexpr float R = 0.70710678118654752440f;
-    cf b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
-    cf b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
-    cf b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
-    cf b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
-    // odd branch pre-twiddles W8^n
-    b5 = {(b5.x + b5.y) * R, (b5.y - b5.x) * R};   // * (1 - i)/sqrt2
-    b6 = mul_mi(b6);                               // * -i
-    b7 = {(b7.y - b7.x) * R, -(b7.x + b7.y) * R};  // * (-1 - i)/sqrt2
+    const cf b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
+    const cf b1 = cadd(v[1], v[5]), c5 = csub(v[1], v[5]);
+    const cf b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
+    const cf b3 = cadd(v[3], v[7]), c7 = csub(v[3], v[7]);
+    // odd branch pre-twiddles W8^n (the one of b6, -i, is folded into its uses)
+    const cf b5 = add_mi(c5, c5) * R;     // * (1 - i)/sqrt2:  ((x + y) R, (y - x) R)
+    const cf b7 = sub_mi(c7, c7) * -R;    // * (-1 - i)/sqrt2: ((y - x) R, -(x + y) R)
     // even outputs: 4-point DFT of b0..b3
-    cf d0 = cadd(b0, b2), d1 = csub(b0, b2), d2 = cadd(b1, b3), d3 = mul_mi(csub(b1, b3));
+    const cf d0 = cadd(b0, b2), d1 = csub(b0, b2), d2 = cadd(b1, b3), d3 = csub(b1, b3);
     v[0] = cadd(d0, d2);
     v[4] = csub(d0, d2);
-    v[2] = cadd(d1, d3);
-    v[6] = csub(d1, d3);
-    // odd outputs: 4-point DFT of b4..b7
-    cf e0 = cadd(b4, b6), e1 = csub(b4, b6), e2 = cadd(b5, b7), e3 = mul_mi(csub(b5, b7));
+    v[2] = add_mi(d1, d3);
+    v[6] = sub_mi(d1, d3);
+    // odd outputs: 4-point DFT of b4, -i b6, b5, b7
+    const cf e0 = add_mi(b4, b6), e1 = sub_mi(b4, b6), e2 = cadd(b5, b7), e3 = csub(b5, b7);
     v[1] = cadd(e0, e2);
     v[5] = csub(e0, e2);
-    v[3] = cadd(e1, e3);
-    v[7] = csub(e1, e3);
+    v[3] = add_mi(e1, e3);
+    v[7] = sub_mi(e1, e3);
 }
 
 // Complex row stride of the two register<->LDS exchanges.  72 (64 + 8) makes the strided column gather of the
@@ -506,11 +524,11 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         for (int n1 = 0; n1 < 8; ++n1) {
             const int i = 64 * n1 + lane;
             const bool in = i < p.frame_len;
-            const float a = ya[i], b = yb[i];
-            v[n1].x = in ? a : 0.f;
-            v[n1].y = (in && has_b) ? b : 0.f;
-            ora |= __builtin_bit_cast(uint32_t, v[n1].x);
-            orb |= __builtin_bit_cast(uint32_t, v[n1].y);
+            const float la = ya[i], lb = yb[i];  // loaded whether or not they are used (see above)
+            const float a = in ? la : 0.f, b = (in && has_b) ? lb : 0.f;
+            v[n1] = cf{a, b};
+            ora |= __builtin_bit_cast(uint32_t, a);  // (bit_cast of a vector ELEMENT reads element 0 with this clang:
+            orb |= __builtin_bit_cast(uint32_t, b);  //  cast the scalars)
         }
         const bool nza = __any((ora << 1) != 0u);
         const bool nzb = __any((orb << 1) != 0u);
