@@ -186,6 +186,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The same for two values at once, the DPP operand fused into the addition (the builtin form costs a move per shift and
+// two extra instructions per row broadcast).  The two chains alternate; with one s_nop a write and the DPP read of the
+// same register are two wait states apart, as the VALU -> DPP hazard requires (inline asm hides it from the compiler).
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+#define KWS_DPP_STEP(ctrl)                                                      \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                                      \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                                      \
+    "s_nop 0\n\t"
+    asm("s_nop 1\n\t"
+        KWS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1, 3 += lane 15 of the row below; rows 0, 2 keep their value
+        KWS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")  // rows 2, 3 += lane 31
+        : "+v"(a), "+v"(b));
+#undef KWS_DPP_STEP
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+}
+
 // First-pass twiddles of this lane, W512^(lane*i).
 __device__ __forceinline__ void load_twiddles(const float2* __restrict__ tw, int lane, cf (&t1)[8]) {
 #pragma unroll
@@ -226,23 +247,33 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
     }
     wave_lds_order();
     const float scale = power ? (1.0f / (4.0f * NFFT)) : 0.25f;
-    ea = 0.f;
-    eb = 0.f;
+    float pa[4], pb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float ar = z[j].x + w[j].x, ai = z[j].y - w[j].y;  // 2*A
         const float br = z[j].y + w[j].y, bi = z[j].x - w[j].x;  // 2*B (up to a unit factor)
-        float pa = fmaf(ar, ar, ai * ai) * scale;
-        float pb = fmaf(br, br, bi * bi) * scale;
+        pa[j] = fmaf(ar, ar, ai * ai) * scale;
+        pb[j] = fmaf(br, br, bi * bi) * scale;
         if (!power) {
-            pa = sqrtf(pa);
-            pb = sqrtf(pb);
+            pa[j] = sqrtf(pa[j]);
+            pb[j] = sqrtf(pb[j]);
         }
-        pa = nza ? pa : 0.f;
-        pb = nzb ? pb : 0.f;
-        pbuf[pslot[j]] = make_float2(pa, pb);
-        ea += pa;
-        eb += pb;
+    }
+    if (!(nza && nzb)) {  // wave-uniform and rare (silence): a real branch, not ten selects on every frame pair
+        asm volatile("" ::: "memory");  // keeps the compiler from converting the branch into selects
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pa[j] = nza ? pa[j] : 0.f;
+            pb[j] = nzb ? pb[j] : 0.f;
+        }
+    }
+    ea = 0.f;
+    eb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pbuf[pslot[j]] = make_float2(pa[j], pb[j]);
+        ea += pa[j];
+        eb += pb[j];
     }
     // bin 256 = Z[256] lives in lane 0, register 4 (k1 = 0, q = 0, d = 4); it is its own mirror image
     if (lane == 0) {
@@ -357,8 +388,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
 
     float ea, eb;
     split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, ea, eb);
-    ea = wave_sum(ea);
-    eb = wave_sum(eb);
+    wave_sum2(ea, eb);
 
     // sparse mel: this lane's chunk of <= 8 bins is one contiguous 64-byte run of the power buffer (four
     // conflict-free ds_read_b128); slots past the chunk's length hold stale finite values and meet zero weights
