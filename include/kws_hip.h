@@ -152,6 +152,15 @@ int kws_stream_state(kws_ctx* ctx, const float** d_feat_ring, int* hops);
 /* Copy the raw feature ring (float32 [n_streams, num_frames, numcep], ring order) into caller memory. */
 int kws_stream_copy_features(kws_ctx* ctx, float* d_out);
 
+/* Energy endpointer for the streams opened with kws_stream_open (build-defined: it stands in for
+ * the webrtcvad endpointing of the reference's live loop, kws/inference/inference_local.py:131-166, with the same
+ * hysteresis at hop granularity).  Call after kws_stream_push_i16.  The hop is voiced when the newest frame's log
+ * energy (cepstrum 0) exceeds the threshold; an utterance opens when more than 80 % of the last on_window hops are
+ * voiced (:151), closes when more than 90 % of the last off_window hops are unvoiced (:161); 400 ms / 800 ms in the
+ * reference = 40 / 80 hops of 10 ms.  d_state int32 [n_streams]: bit 0 = inside an utterance, bits 1-2 = event at
+ * this hop (1 opened, 2 closed).  The history lives in the context; kws_stream_open or a change of windows resets it. */
+int kws_stream_vad_f32(kws_ctx* ctx, float log_energy_threshold, int on_window, int off_window, int32_t* d_state);
+
 /* ---- cnn-trad-fpool3 (build-defined: the reference only names the model, test.py:80) ----
  * Sainath & Parada's cnn-trad-fpool3 on the [1,99,10] MFCC map with SAME padding: conv 64 x (20x8) + ReLU,
  * max-pool 1x3 over frequency, conv 64 x (10x4) + ReLU, flatten, Linear 32, Linear 128 + ReLU, Linear C.

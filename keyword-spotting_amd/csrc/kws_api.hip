@@ -187,6 +187,10 @@ struct kws_ctx {
     float* d_post_sum = nullptr;
     int* d_post_count = nullptr;
     int post_window = 0, post_classes = 0;
+    // energy endpointer (kws_stream_vad_f32): voiced flags [n_streams][off_window], (cursor, triggered) [n_streams][2]
+    unsigned char* d_vad_flags = nullptr;
+    int* d_vad_state = nullptr;
+    int vad_on = 0, vad_off = 0;
 
     // profiling
     bool prof = false;
@@ -628,8 +632,17 @@ static void smooth_free(kws_ctx* c) {
     c->post_window = c->post_classes = 0;
 }
 
+static void vad_free(kws_ctx* c) {
+    if (c->d_vad_flags) (void)hipFree(c->d_vad_flags);
+    if (c->d_vad_state) (void)hipFree(c->d_vad_state);
+    c->d_vad_flags = nullptr;
+    c->d_vad_state = nullptr;
+    c->vad_on = c->vad_off = 0;
+}
+
 static void stream_free(kws_ctx* c) {
     smooth_free(c);
+    vad_free(c);
     if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
     if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
     if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
@@ -806,6 +819,33 @@ int kws_infer_cnn_trad_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_log
     rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
     if (rc) return rc;
     return kws_forward_cnn_trad_f32(c, c->d_feat_ws, B, d_logits, d_label);
+}
+
+int kws_stream_vad_f32(kws_ctx* c, float log_energy_threshold, int on_window, int off_window, int32_t* d_state) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_vad_f32: call kws_stream_open first");
+    if (!d_state) return fail(c, KWS_EINVAL, "kws_stream_vad_f32: d_state is NULL");
+    if (on_window < 1 || off_window < on_window || off_window > 1024)
+        return fail(c, KWS_EINVAL, "kws_stream_vad_f32: need 1 <= on_window <= off_window <= 1024");
+    if (!c->fp.append_energy) return fail(c, KWS_EUNSUPPORTED, "kws_stream_vad_f32: needs cepstrum 0 = log frame energy (appendEnergy)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (on_window != c->vad_on || off_window != c->vad_off) {  // (re)start the history
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        vad_free(c);
+        const size_t fb = (size_t)c->n_streams * off_window, sb = sizeof(int) * 2 * (size_t)c->n_streams;
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_vad_flags), fb) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&c->d_vad_state), sb) != hipSuccess) {
+            vad_free(c);
+            return fail(c, KWS_ENOMEM, "kws_stream_vad_f32: device allocation failed");
+        }
+        HIP_TRY(c, hipMemsetAsync(c->d_vad_flags, 0, fb, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_vad_state, 0, sb, c->stream));
+        c->vad_on = on_window;
+        c->vad_off = off_window;
+    }
+    HIP_TRY(c, launch_stream_vad(c->stream, c->d_feat_ring, c->d_hops, c->n_streams, c->fp.num_frames, c->fp.numcep,
+                                 log_energy_threshold, on_window, off_window, c->d_vad_flags, c->d_vad_state, d_state));
+    return KWS_OK;
 }
 
 int kws_softmax_f32(kws_ctx* c, const float* d_logits, int B, int C, float* d_prob) {

@@ -937,6 +937,52 @@ hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, fl
     return hipGetLastError();
 }
 
+// Energy endpointer per stream (the gate that replaces webrtcvad in the reference's live loop,
+// kws/inference/inference_local.py:131-166 -- same hysteresis, at hop granularity).  The newest frame's log energy
+// (cepstrum 0 with appendEnergy) above the threshold marks the hop voiced; an utterance OPENS when more than 80 % of the
+// last `on_window` hops are voiced (:151) and CLOSES when more than 90 % of the last `off_window` hops are unvoiced
+// (:161); hops before the stream began count as unvoiced (the reference's rings start as zeros).  One thread per stream.
+// state[s] = triggered | event << 1, event 1 = opened at this hop, 2 = closed at this hop.
+__global__ void kws_stream_vad_kernel(const float* __restrict__ feat_ring, const int* __restrict__ hops_ptr, int n_streams,
+                                      int num_frames, int numcep, float threshold, int on_window, int off_window,
+                                      unsigned char* __restrict__ flags, int* __restrict__ cursor_trig, int32_t* __restrict__ state) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const int hops = *hops_ptr;  // already advanced by the push this call follows: the newest frame is hops - 3
+    if (hops < 3) {              // no complete frame yet
+        state[s] = 0;
+        return;
+    }
+    const float c0 = feat_ring[((size_t)s * num_frames + (hops - 3) % num_frames) * numcep];
+    unsigned char* fl = flags + (size_t)s * off_window;
+    const int cur = cursor_trig[2 * s];
+    int trig = cursor_trig[2 * s + 1];
+    fl[cur % off_window] = c0 > threshold ? 1 : 0;
+    int n_on = 0, n_all = 0;
+    for (int k = 0; k < off_window; ++k) {  // k hops back from the newest
+        const int v = k <= cur ? fl[(cur - k) % off_window] : 0;
+        n_all += v;
+        if (k < on_window) n_on += v;
+    }
+    int event = 0;
+    if (!trig) {
+        if (10 * n_on > 8 * on_window) trig = 1, event = 1;
+    } else if (10 * (off_window - n_all) > 9 * off_window) {
+        trig = 0, event = 2;
+    }
+    cursor_trig[2 * s] = cur + 1;
+    cursor_trig[2 * s + 1] = trig;
+    state[s] = trig | (event << 1);
+}
+
+hipError_t launch_stream_vad(hipStream_t s, const float* d_feat_ring, const int* d_hops, int n_streams, int num_frames, int numcep,
+                             float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
+                             int32_t* d_state) {
+    hipLaunchKernelGGL(kws_stream_vad_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, s, d_feat_ring, d_hops, n_streams,
+                       num_frames, numcep, threshold, on_window, off_window, d_flags, d_cursor_trig, d_state);
+    return hipGetLastError();
+}
+
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label) {
     hipLaunchKernelGGL(kws_smooth_posteriors_kernel, dim3((S + 63) / 64), dim3(64), 0, s, d_logits, S, C, window, d_ring, d_sum,

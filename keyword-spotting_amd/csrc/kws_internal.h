@@ -136,6 +136,9 @@ hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const fl
 hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label);
+hipError_t launch_stream_vad(hipStream_t s, const float* d_feat_ring, const int* d_hops, int n_streams, int num_frames, int numcep,
+                             float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
+                             int32_t* d_state);
 
 extern const char* const kKernelNames[KWS_K_COUNT];
 

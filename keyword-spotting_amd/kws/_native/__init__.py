@@ -51,6 +51,7 @@ SIGNATURES = {
     "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
     "kws_load_cnn_trad": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
+    "kws_stream_vad_f32": (C.c_int, [_c_ctx, C.c_float, C.c_int, C.c_int, _i32p]),
     "kws_forward_cnn_trad_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_cnn_trad_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_softmax_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p]),
@@ -200,6 +201,9 @@ class Context:
     def stream_smooth_f32(self, logits, window, smoothed, label=None):
         self._check(self._lib.kws_stream_smooth_f32(self._h, _ptr(logits), int(logits.shape[1]), int(window), _ptr(smoothed),
                                                     _ptr(label) if label is not None else None), ModelError)
+
+    def stream_vad_f32(self, threshold, on_window, off_window, state):
+        self._check(self._lib.kws_stream_vad_f32(self._h, float(threshold), int(on_window), int(off_window), _ptr(state)), ModelError)
 
     def set_pointwise_math(self, math):
         self._check(self._lib.kws_set_pointwise_math(self._h, int(math)), ModelError)

@@ -139,7 +139,8 @@ class StreamingSpotter:
     """
 
     def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
-                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False, smooth_window: int = 0):
+                 config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False, smooth_window: int = 0,
+                 vad_log_energy: Optional[float] = None, vad_windows: Tuple[int, int] = (40, 80)):
         from kws import _native
 
         self.config = config or AudioConfig()
@@ -159,6 +160,13 @@ class StreamingSpotter:
         # `smooth_window` hops per stream on the device (kws_stream_smooth_f32); 0 = raw logits / argmax
         self.smooth_window = int(smooth_window)
         self._smoothed = torch.zeros_like(self._logits) if self.smooth_window > 0 else None
+        # energy endpointer (stands in for the reference's webrtcvad gate,
+        # kws/inference/inference_local.py:131-166): per stream, bit 0 of `vad_state` = inside an utterance,
+        # bits 1-2 = opened (1) / closed (2) at the last hop; None = off
+        self.vad_log_energy = vad_log_energy
+        self.vad_windows = (int(vad_windows[0]), int(vad_windows[1]))
+        self._vad = torch.zeros((self.n_streams,), dtype=torch.int32, device=self.device) if vad_log_energy is not None else None
+        self.vad_state: Optional[np.ndarray] = None
         torch.cuda.synchronize(self.device)
 
     def push(self, samples) -> Tuple[np.ndarray, np.ndarray]:
@@ -170,12 +178,20 @@ class StreamingSpotter:
         self._hop_buf.copy_(x, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()  # the context runs on its own stream
         self._ctx.stream_push_i16(self._hop_buf, self._logits, self._labels, use_graph=self.use_graph)
+        if self._vad is not None:
+            self._ctx.stream_vad_f32(self.vad_log_energy, self.vad_windows[0], self.vad_windows[1], self._vad)
         if self.smooth_window > 0:
             self._ctx.stream_smooth_f32(self._logits, self.smooth_window, self._smoothed, self._labels)
             self._ctx.sync()
+            self._fetch_vad()
             return self._labels.cpu().numpy(), self._smoothed.cpu().numpy()
         self._ctx.sync()
+        self._fetch_vad()
         return self._labels.cpu().numpy(), self._logits.cpu().numpy()
+
+    def _fetch_vad(self):
+        if self._vad is not None:
+            self.vad_state = self._vad.cpu().numpy()
 
     def features(self) -> np.ndarray:
         """The current windows, oldest frame first: float32 [S, 99, 10] (zeros where no frame exists yet)."""

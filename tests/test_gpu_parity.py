@@ -658,3 +658,45 @@ def test_cnn_trad_fpool3_fused_wav_to_label(dev):
     assert torch.equal(two_call, logits)
     with pytest.raises(ModelError):
         m.infer_pcm16(wav.cpu())
+
+
+def test_streaming_energy_endpointer(dev):
+    """kws_stream_vad_f32 against oracle.endpointer fed with the oracle's own log energies: three streams (silence,
+    a loud burst in silence, continuous noise) over 260 hops; open / close events at the same hops."""
+    from kws.inference import StreamingSpotter
+    from oracle.endpointer import EnergyEndpointer
+
+    hops, step, S = 260, 160, 3
+    rng = np.random.default_rng(11)
+    pcm = np.zeros((S, hops * step), np.int16)
+    pcm[1, 60 * step:140 * step] = rng.integers(-20000, 20000, 80 * step)
+    pcm[2] = rng.integers(-20000, 20000, hops * step)
+    thr = -10.0  # silence sits at log(eps) = -36, the noise at about -1.8 (float PCM in [-1, 1))
+    sp = StreamingSpotter(S, vad_log_energy=thr)
+    try:
+        refs = [EnergyEndpointer(thr) for _ in range(S)]
+        # log energies of all frames from the whole signals: pre-emphasis runs over the continuous stream, so a frame
+        # that starts right after the burst still sees its last sample
+        c0_all = [o_mfcc.mfcc(o_mfcc.pcm16_to_float(pcm[s]), o_mfcc.FrontendSpec(n_samples=pcm.shape[1]))[:, 0] for s in range(S)]
+        got_events = [[] for _ in range(S)]
+        want_events = [[] for _ in range(S)]
+        for t in range(hops):
+            sp.push(pcm[:, t * step:(t + 1) * step])
+            for s in range(S):
+                st = int(sp.vad_state[s])
+                if st >> 1:
+                    got_events[s].append((t, st >> 1))
+                if t < 2:  # no complete frame yet: the device reports 0 and keeps its history untouched
+                    assert st == 0
+                    continue
+                c0 = c0_all[s][t - 2]
+                trig, ev = refs[s].update(float(c0))
+                assert abs(c0 - thr) > 3.0  # the decision is never close to the threshold
+                assert (st & 1) == int(trig), (s, t)
+                if ev:
+                    want_events[s].append((t, ev))
+        assert got_events == want_events
+        assert want_events[0] == [] and len(want_events[1]) == 2 and len(want_events[2]) == 1
+        assert want_events[1][0][1] == 1 and want_events[1][1][1] == 2
+    finally:
+        sp.close()

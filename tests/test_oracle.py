@@ -184,3 +184,19 @@ def test_dscnn_double_precision_agrees():
     st = o_dscnn.random_state(seed=4)
     x = torch.randn(4, 1, 99, 10)
     np.testing.assert_allclose(o_dscnn.forward(st, x).numpy(), o_dscnn.forward(st, x.double()).numpy(), atol=5e-6)
+
+
+def test_endpointer_known_answer():
+    """The endpointer's hysteresis (reference thresholds, inference_local.py:151,161): a 100-hop voiced stretch in
+    silence opens after 33 voiced hops of the 40-hop window and closes after 73 unvoiced hops of the 80-hop window."""
+    from oracle.endpointer import EnergyEndpointer
+
+    e = EnergyEndpointer(-10.0)
+    events = []
+    for t in range(300):
+        trig, ev = e.update(0.0 if 50 <= t < 150 else -36.0)
+        if ev:
+            events.append((t, ev))
+    assert events == [(82, 1), (222, 2)]
+    short = EnergyEndpointer(-10.0)
+    assert not any(short.update(0.0 if 10 <= t < 40 else -36.0)[0] for t in range(200))  # 30 voiced hops never reach 80 % of 40
