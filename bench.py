@@ -80,6 +80,18 @@ def synth_weights(seed: int = 1, std: float = 0.1) -> np.ndarray:
     return (np.random.RandomState(seed).standard_normal(n) * std).astype(np.float32)
 
 
+def synth_cnn_trad_weights(seed: int = 1) -> np.ndarray:
+    """Random-init cnn-trad-fpool3 in state_dict order (conv1, conv2, lin, dnn, fc; weight then bias): fan-in scaled
+    normal weights so activations stay O(1) through the 2560- and 19008-wide sums, N(0, 0.1) biases."""
+    rs = np.random.RandomState(seed)
+    parts = []
+    for shape in ((64, 1, 20, 8), (64, 64, 10, 4), (32, 64 * 99 * 3), (128, 32), (NUM_CLASSES, 128)):
+        fan_in = int(np.prod(shape[1:]))
+        parts.append(rs.standard_normal(int(np.prod(shape))) * (2.0 / fan_in) ** 0.5)
+        parts.append(rs.standard_normal(shape[0]) * 0.1)
+    return np.concatenate(parts).astype(np.float32)
+
+
 def synth_clips(batch: int, seed: int) -> np.ndarray:
     return np.random.default_rng(seed).integers(-32768, 32768, size=(batch, N_SAMPLES), dtype=np.int16)
 
@@ -161,7 +173,7 @@ def cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, state, logits):
         n = min(args.cpu_sample, B, 256)
         t0 = time.perf_counter()
         feats = o_mfcc.collate_pcm16(clips[:n])
-        want = o_ct.forward(state, torch.from_numpy(feats)).numpy()
+        want = o_ct.forward(o_ct.unflatten_state(state, NUM_CLASSES), torch.from_numpy(feats)).numpy()
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{n} of the step's clips: oracle MFCC (NumPy, per clip) + torch-CPU cnn-trad-fpool3"}
@@ -214,10 +226,8 @@ def main():
     ctx = _native.Context(local_rank)
     ct_state = None
     if args.model == "cnn-trad-fpool3":
-        from oracle import cnn_trad as o_ct  # weight generator + CPU baseline only (test infrastructure)
-
-        ct_state = o_ct.random_state(seed=1)
-        ctx.load_cnn_trad(o_ct.flatten_state(ct_state), NUM_CLASSES)
+        ct_state = synth_cnn_trad_weights()
+        ctx.load_cnn_trad(ct_state, NUM_CLASSES)
         step = lambda: ctx.infer_cnn_trad_i16(wav, logits, labels)
     else:
         ctx.load_dscnn(blob, NUM_CLASSES)

@@ -57,3 +57,14 @@ def forward(state: dict, x: torch.Tensor, return_layers: bool = False):
 
 def flatten_state(state: dict) -> np.ndarray:
     return np.concatenate([state[k].detach().to(torch.float32).reshape(-1).numpy() for k in state_shapes(state["fc.bias"].numel())])
+
+
+def unflatten_state(blob: np.ndarray, num_classes: int = 12) -> "OrderedDict[str, torch.Tensor]":
+    """Inverse of ``flatten_state``: the ten tensors from one float32 vector in state_dict order."""
+    out, o = OrderedDict(), 0
+    for k, shp in state_shapes(num_classes).items():
+        n = int(np.prod(shp))
+        out[k] = torch.from_numpy(np.asarray(blob[o:o + n], dtype=np.float32).reshape(shp).copy())
+        o += n
+    assert o == len(blob)
+    return out

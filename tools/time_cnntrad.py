@@ -6,11 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "keyword-spotting_amd"))
 import bench
 from kws import _native
-from oracle import cnn_trad as o_ct
+
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
 ctx = _native.Context(0); ctx.use_torch_stream()
-ctx.load_cnn_trad(o_ct.flatten_state(o_ct.random_state(4)), 12)
+ctx.load_cnn_trad(bench.synth_cnn_trad_weights(4), 12)
 wav = torch.from_numpy(bench.synth_clips(B, 0)).to(dev)
 feat = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
 ctx.mfcc_i16(wav, feat)
