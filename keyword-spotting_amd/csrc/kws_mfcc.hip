@@ -440,13 +440,34 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
         if (i < p.numcep && (f == 0 || has_b)) {
             const float4* L4 = reinterpret_cast<const float4*>(lbuf + 64 * f);
             const float4* D4 = reinterpret_cast<const float4*>(dctb + i * nfp);
+            // the reference row length (26 filters -> 7 float4) gets a compile-time trip count: loads in batches of
+            // four pairs ahead of their multiply-adds (two LDS round trips instead of seven; same order of additions)
             float acc = 0.f;
-            for (int j = 0; j < nfp / 4; ++j) {
-                const float4 d = D4[j], l = L4[j];
-                acc = fmaf(d.x, l.x, acc);
-                acc = fmaf(d.y, l.y, acc);
-                acc = fmaf(d.z, l.z, acc);
-                acc = fmaf(d.w, l.w, acc);
+            if (nfp == 28) {
+#pragma unroll
+                for (int j0 = 0; j0 < 7; j0 += 4) {
+                    float4 d[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j0 + j < 7) d[j] = D4[j0 + j], l[j] = L4[j0 + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j0 + j < 7) {
+                            acc = fmaf(d[j].x, l[j].x, acc);
+                            acc = fmaf(d[j].y, l[j].y, acc);
+                            acc = fmaf(d[j].z, l[j].z, acc);
+                            acc = fmaf(d[j].w, l[j].w, acc);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int j = 0; j < nfp / 4; ++j) {
+                    const float4 d = D4[j], l = L4[j];
+                    acc = fmaf(d.x, l.x, acc);
+                    acc = fmaf(d.y, l.y, acc);
+                    acc = fmaf(d.z, l.z, acc);
+                    acc = fmaf(d.w, l.w, acc);
+                }
             }
             if (i == 0) {
                 if (p.append_energy) {
