@@ -132,6 +132,46 @@ def cpu_baseline(clips: np.ndarray, blob: np.ndarray):
     }, logits.numpy()
 
 
+def mfcc_only_line(args, world, B, elapsed, ctx, _native, clips, feat_out):
+    """The JSON line of `--model mfcc-only` (BASELINE.json configs[1]: the MFCC kernel alone, vs the CPU)."""
+    m_ms, m_n = ctx.prof_read(_native.KWS_K_MFCC)
+    mfcc_s = (m_ms / max(m_n, 1)) * 1e-3
+    value = B * world * args.steps / elapsed
+    achieved = B * BYTES_PER_CLIP / mfcc_s / 1e9 if mfcc_s > 0 else 0.0
+    out = {
+        "metric": "1s 16kHz clips/sec, MFCC only (wav->features)", "value": value, "unit": "clips/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "C2: batch=4096/GPU synthetic uniform int16 1s/16kHz clips, device-resident, MFCC(400/160/512, "
+                        "26 mel, 10 cep) -> float32 [B,1,99,10]",
+            "clips_per_gpu_per_step": B,
+            "sharding": f"{world} independent shard(s), no data-path collective",
+        },
+        "roofline": {
+            "kernel": _native.kernel_name(_native.KWS_K_MFCC), "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_BPS / 1e9,
+            "unit": "GB/s", "frac": achieved / (PEAK_HBM_BPS / 1e9), "traffic": pmc_traffic(_native.kernel_name(_native.KWS_K_MFCC)),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP, "avg_kernel_ms": mfcc_s * 1e3, "launches": m_n,
+            "note": "algorithmic HBM read (32 000 B per clip) over the kernel's duration against the 8 TB/s spec peak, the "
+                    "roofline BASELINE.json declares; the kernel is LDS/VALU-bound (DESIGN.md 4.1): "
+                    f"{B / mfcc_s * MFCC_FLOP_PER_CLIP / 1e12 if mfcc_s > 0 else 0.0:.1f} TFLOP/s of 157.3 f32",
+        },
+    }
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import psf_mfcc as o_mfcc
+
+        n = min(args.cpu_sample, B)
+        o_mfcc.collate_pcm16(clips[:4])
+        t0 = time.perf_counter()
+        want = o_mfcc.collate_pcm16(clips[:n])
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "clips/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} of the step's clips once: per-clip NumPy MFCC loop (the reference's structure)"}
+        out["parity_vs_cpu_max_abs_mfcc_err"] = float(np.abs(feat_out[:n].cpu().numpy() - want).max())
+    return out
+
+
 def cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, state, logits):
     """The JSON line of `--model cnn-trad-fpool3` (BASELINE.json configs[2] read literally; not the driver's line)."""
     c_ms, c_n = ctx.prof_read(_native.KWS_K_CNNTRAD_CONV)
@@ -189,9 +229,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="clips timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--model", choices=["ds-cnn", "cnn-trad-fpool3"], default="ds-cnn",
+    ap.add_argument("--model", choices=["ds-cnn", "cnn-trad-fpool3", "mfcc-only"], default="ds-cnn",
                     help="ds-cnn: the reference's model (the driver's line); cnn-trad-fpool3: the build-defined model "
-                         "BASELINE.json configs[2] names (parity unpinned against the reference, DESIGN.md 4.5)")
+                         "BASELINE.json configs[2] names (parity unpinned against the reference, DESIGN.md 4.5); "
+                         "mfcc-only: BASELINE.json configs[1], the front end alone, priced against the HBM-read roofline")
     args = ap.parse_args()
 
     import torch
@@ -225,7 +266,11 @@ def main():
     blob = synth_weights()
     ctx = _native.Context(local_rank)
     ct_state = None
-    if args.model == "cnn-trad-fpool3":
+    feat_out = None
+    if args.model == "mfcc-only":
+        feat_out = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
+        step = lambda: ctx.mfcc_i16(wav, feat_out)
+    elif args.model == "cnn-trad-fpool3":
         ct_state = synth_cnn_trad_weights()
         ctx.load_cnn_trad(ct_state, NUM_CLASSES)
         step = lambda: ctx.infer_cnn_trad_i16(wav, logits, labels)
@@ -256,7 +301,9 @@ def main():
     m_ms, m_n = ctx.prof_read(_native.KWS_K_MFCC)
     ctx.prof_enable(False)
 
-    if rank == 0 and args.model == "cnn-trad-fpool3":
+    if rank == 0 and args.model == "mfcc-only":
+        print(json.dumps(mfcc_only_line(args, world, B, elapsed, ctx, _native, clips, feat_out)), flush=True)
+    elif rank == 0 and args.model == "cnn-trad-fpool3":
         print(json.dumps(cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, ct_state, logits)), flush=True)
     elif rank == 0:
         total_clips = B * world * args.steps
