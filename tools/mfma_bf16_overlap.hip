@@ -49,6 +49,8 @@ __global__ void k(float* out, unsigned long long* cyc, int iters) {
                         if (OP == 12) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(f[i]) : "s"(0xffff0000u), "v"(b));
                         if (OP == 13) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[i]) : "v"(b));
                         if (OP == 14) asm volatile("v_exp_f32 %0, %0" : "+v"(f[i]));
+                        if (OP == 15) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(f[i]) : "v"(b), "s"(0xbf800000u));
+                        if (OP == 16) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(f[i]) : "v"(b));
                     }
                 }
             }
@@ -102,5 +104,10 @@ int main() {
     run<2, 3>("bf16 MFMA + v_and_b32");
     run<2, 4>("bf16 MFMA + v_perm_b32");
     run<2, 6>("bf16 MFMA + v_fmac_dpp");
+    run<1, 15>("v_fma_mix_f32 alone");
+    run<2, 15>("bf16 MFMA + v_fma_mix_f32");
+    run<1, 16>("v_cvt_pkrtz_f16_f32 alone");
+    run<2, 16>("bf16 MFMA + v_cvt_pkrtz_f16");
+    run<2, 5>("bf16 MFMA + v_sub_f32");
     return 0;
 }
