@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$REPO" && timeout -k 10 400 python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python $REPO/bench.py --steps 20 --warmup 3 --cpu-sample 0 > "$OUT/kt.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python $REPO/bench.py --steps 200 --warmup 20 --cpu-sample 0 > "$OUT/kt.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 0 > "$OUT/fetch.log" 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o write -- python $REPO/bench.py --steps 5 --warmup 1 --cpu-sample 0 > "$OUT/write.log" 2>&1 || exit 1
 find "$OUT/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_bench_kernel_stats.csv" \;
