@@ -2,7 +2,7 @@
 """Throughput of the keyword-spotting hot path on MI355X: 1 s / 16 kHz clips per second, end to end
 (device-resident int16 PCM -> MFCC -> DS-CNN -> logits + label), BASELINE.json's metric.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,7 +11,9 @@ over one batch of 4096 synthetic clips per GPU (BASELINE.json configs[2], the en
 configuration; the model is the reference's DS-CNN -- "cnn-trad-fpool3" does not exist in the
 reference).  Clips are independent, so N GPUs = N shards with no collective on
 the data path (weak scaling); torch.distributed is used only for the barrier and the max-over-ranks
-of the timed region.  Rank 0 prints ONE JSON line.
+of the timed region.  Rank 0 prints ONE JSON line.  Before the W warm-up steps the step runs `--spinup` more untimed
+times (default 60): from idle the GPU needs ~30 steps for its clocks to settle, and the timed K steps should see the
+steady state whatever W the caller picked.
 """
 import argparse
 import json
@@ -147,6 +149,7 @@ def mfcc_only_line(args, world, B, elapsed, ctx, _native, clips, feat_out):
                         "26 mel, 10 cep) -> float32 [B,1,99,10]",
             "clips_per_gpu_per_step": B,
             "sharding": f"{world} independent shard(s), no data-path collective",
+            "spinup_steps": args.spinup,
         },
         "roofline": {
             "kernel": _native.kernel_name(_native.KWS_K_MFCC), "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_BPS / 1e9,
@@ -190,6 +193,7 @@ def cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, state, logits):
                         "-> logits+label",
             "clips_per_gpu_per_step": B,
             "sharding": f"{world} independent shard(s), no data-path collective",
+            "spinup_steps": args.spinup,
         },
         "roofline": {
             "kernel": _native.kernel_name(_native.KWS_K_CNNTRAD_CONV), "bound": "mfma",
@@ -225,8 +229,11 @@ def cnn_trad_line(args, world, B, elapsed, ctx, _native, clips, state, logits):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup", type=int, default=60,
+                    help="untimed steps before the warm-up: from idle the GPU's clocks take ~30 steps (20 ms) to settle "
+                         "(per-step time 0.82 -> 0.67 ms, tools/ramp_probe.py); reported as config.spinup_steps")
     ap.add_argument("--batch", type=int, default=4096, help="clips per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="clips timed on the CPU baseline (0 = skip)")
     ap.add_argument("--model", choices=["ds-cnn", "cnn-trad-fpool3", "mfcc-only"], default="ds-cnn",
@@ -282,7 +289,7 @@ def main():
     logits = torch.empty((B, NUM_CLASSES), dtype=torch.float32, device=dev)
     labels = torch.empty((B,), dtype=torch.int32, device=dev)
 
-    for _ in range(args.warmup):
+    for _ in range(args.spinup + args.warmup):
         step()
     ctx.sync()
     ctx.prof_enable(True)
@@ -329,6 +336,7 @@ def main():
                             "MFCC(400/160/512, 26 mel, 10 cep) + DS-CNN(12 classes, random-init N(0,0.1)) -> logits+label",
                 "clips_per_gpu_per_step": B,
                 "sharding": f"{world} independent shard(s), no data-path collective",
+                "spinup_steps": args.spinup,
             },
             "roofline": {
                 "kernel": _native.kernel_name(_native.KWS_K_DSCNN),

@@ -1,0 +1,18 @@
+import os, sys, numpy as np, torch
+ROOT='/root/repo'; sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'keyword-spotting_amd'))
+import bench
+from kws import _native
+dev = torch.device('cuda',0)
+ctx = _native.Context(0); ctx.use_torch_stream()
+ctx.load_dscnn(bench.synth_weights(), 12); ctx.reserve(4096)
+wav = torch.from_numpy(bench.synth_clips(4096,0)).to(dev)
+logits = torch.empty((4096,12), dtype=torch.float32, device=dev); labels = torch.empty((4096,), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+evs=[torch.cuda.Event(enable_timing=True) for _ in range(121)]
+evs[0].record()
+for i in range(120):
+    ctx.infer_i16(wav, logits, labels); evs[i+1].record()
+torch.cuda.synchronize()
+d=[evs[i].elapsed_time(evs[i+1]) for i in range(120)]
+print('per-step ms:', ' '.join(f'{x:.3f}' for x in d[:30]))
+print('steps 30-59 mean', np.mean(d[30:60]), ' 60-119 mean', np.mean(d[60:]))
