@@ -771,6 +771,19 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     }
     block_phase<4, MODE>(w, lds, tid, wa);
     stamp();  // 10
+    // The classifier row of lane c (wavefront 0) and the ring bias of channel tid are requested BEFORE the barrier:
+    // their L2 round trips pass while the workgroup waits for its slowest wavefront, instead of sitting exposed at
+    // the very end of the clip (the CU cannot take its next clip before this wavefront is done).
+    const int C = w.num_classes;
+    float4 fcw[CH / 4];
+    float fcb = 0.f, ring_b = 0.f;
+    if (wv == 0 && lane < C) {
+        const float4* wr = reinterpret_cast<const float4*>(w.fc_w + lane * CH);
+#pragma unroll
+        for (int c = 0; c < CH / 4; ++c) fcw[c] = wr[c];
+        fcb = w.fc_b[lane];
+    }
+    if (tid < CH) ring_b = w.pw_b[3 * CH + tid];
     __syncthreads();
     stamp();  // 11
 
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 #pragma unroll
         for (int k = 0; k < NW; ++k) s += lds[OFF_POOLBUF + k * CH + tid];
         constexpr float RING_N = 55.f * 11.f - 53.f * 9.f;  // 128
-        s = fmaf(RING_N, relu(w.pw_b[3 * CH + tid]), s) * (1.0f / (55.f * 11.f));
+        s = fmaf(RING_N, relu(ring_b), s) * (1.0f / (55.f * 11.f));
         pooled[tid] = s;
         if (a) a[tid] = s;
     }
@@ -789,15 +802,13 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     // ---- Linear(64 -> C) + argmax (first maximum wins) on wavefront 0 ------------------------------
     if (wv == 0) {
-        const int C = w.num_classes;
         float v = -INFINITY;
         if (lane < C) {
-            float acc = w.fc_b[lane];
-            const float4* wr = reinterpret_cast<const float4*>(w.fc_w + lane * CH);
+            float acc = fcb;
             const float4* pl = reinterpret_cast<const float4*>(pooled);
 #pragma unroll
             for (int c = 0; c < CH / 4; ++c) {
-                const float4 a4 = wr[c], p4 = pl[c];
+                const float4 a4 = fcw[c], p4 = pl[c];
                 acc = fmaf(a4.x, p4.x, acc);
                 acc = fmaf(a4.y, p4.y, acc);
                 acc = fmaf(a4.z, p4.z, acc);
@@ -806,16 +817,18 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             logits[(size_t)clip * C + lane] = acc;
             v = acc;
         }
-        int idx = lane < C ? lane : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(v, o, 64);
-            const int oi = __shfl_xor(idx, o, 64);
-            if (ov > v || (ov == v && oi < idx)) {
-                v = ov;
-                idx = oi;
-            }
-        }
+        // argmax, first maximum wins: wave maximum by DPP (no LDS round trips; six dependent __shfl_xor rounds through
+        // ds_bpermute were 1.4 k of the 2.6 k cycles this tail took), then the lowest lane that holds it
+        float m = v;
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x111, 0xf, 0xf, false)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x112, 0xf, 0xf, false)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x114, 0xf, 0xf, false)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x118, 0xf, 0xf, false)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x142, 0xa, 0xf, false)));
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), 0x143, 0xc, 0xf, false)));
+        const float vmax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
+        const unsigned long long holders = __ballot(lane < C && v == vmax);
+        const int idx = holders ? __ffsll(holders) - 1 : 0;  // all-NaN logits: label 0
         if (label && lane == 0) label[clip] = idx;
     }
     stamp();  // 12: pool + fc + argmax done
