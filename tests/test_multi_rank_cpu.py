@@ -39,3 +39,19 @@ def test_weights_and_clips_are_seeded():
     assert bench.synth_weights().shape == (26444,)
     assert np.array_equal(bench.synth_clips(3, 5), bench.synth_clips(3, 5))
     assert bench.synth_clips(2, 0).dtype == np.int16
+
+
+def test_cnn_trad_bench_weights_match_the_oracle_layout():
+    """bench.py builds the cnn-trad-fpool3 blob itself (the oracle may only serve its cpu_baseline leg): same size and
+    tensor order as the oracle's state_dict, so unflatten_state reads it back tensor by tensor."""
+    import numpy as np
+
+    from oracle import cnn_trad as o_ct
+
+    blob = bench.synth_cnn_trad_weights(seed=3)
+    shapes = o_ct.state_shapes(bench.NUM_CLASSES)
+    assert blob.dtype == np.float32 and blob.size == sum(int(np.prod(s)) for s in shapes.values())
+    state = o_ct.unflatten_state(blob, bench.NUM_CLASSES)
+    assert list(state) == list(shapes) and all(tuple(state[k].shape) == shapes[k] for k in shapes)
+    assert np.array_equal(o_ct.flatten_state(state), blob)
+    assert abs(float(state["conv2.weight"].std()) - (2.0 / 2560) ** 0.5) < 2e-3  # fan-in scaled
