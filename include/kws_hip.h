@@ -125,11 +125,12 @@ int kws_set_pointwise_math(kws_ctx* ctx, int math);
 
 /* Debug/parity aid: run the DS-CNN and also store every stored activation per clip to d_act
  * (float32 [B, KWS_ACT_FLOATS_PER_CLIP]): conv1 out [64][47*3], block1 out interior [64][47*3],
- * block2 out interior [64][49*5], block3 out interior [64][51*7], pooled mean [64].  "Interior" =
+ * block2 out interior [64][49*5], block3 out interior [64][51*7], pooled mean [64], block4 out interior
+ * [64][53*9] (never stored by the product kernel: it is pooled in registers).  "Interior" =
  * the pointwise output without the relu(bias) ring its padding=1 adds (models.py:104-106).
  * use_mfma: KWS_PW_SPLIT_BF16 (4) / KWS_PW_F32 (1) = the two matrix-core kernels, 0 = a variant whose
  * pointwise / conv1 GEMMs run on the VALU (an independent check of the matrix-core operand mappings). */
-#define KWS_ACT_FLOATS_PER_CLIP (64 * (141 + 141 + 245 + 357) + 64)
+#define KWS_ACT_FLOATS_PER_CLIP (64 * (141 + 141 + 245 + 357) + 64 + 64 * 477)
 int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label,
                           float* d_act, int use_mfma);
 

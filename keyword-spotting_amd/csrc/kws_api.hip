@@ -150,6 +150,7 @@ struct kws_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t order_ev = nullptr;  // orders the new stream behind the old one in kws_set_stream
     std::string err;
 
     // front end
@@ -248,6 +249,7 @@ struct ProfScope {
 };
 
 static void stream_free_fwd(kws_ctx* c);
+static void drop_stream_graph(kws_ctx* c);
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -303,21 +305,29 @@ void kws_destroy(kws_ctx* c) {
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_cnntrad) (void)hipFree(c->d_cnntrad);
     if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
-    if (c->d_post_ring) (void)hipFree(c->d_post_ring);
-    if (c->d_post_sum) (void)hipFree(c->d_post_sum);
-    if (c->d_post_count) (void)hipFree(c->d_post_count);
     if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
-    if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
-    if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
-    if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
-    if (c->d_hops) (void)hipFree(c->d_hops);
+    stream_free_fwd(c);  // rings, hop counter, captured graph, smoothing and endpointer history
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
+// The workspaces and tables of a context are shared by everything it enqueues, so work enqueued on the new stream must
+// not overtake work still pending on the old one: the new stream waits on an event recorded on the old stream.  (A
+// context is still single-threaded and serves one stream at a time; this only makes the hand-over safe.)
 int kws_set_stream(kws_ctx* c, void* hip_stream, int external) {
     if (!c) return KWS_EINVAL;
-    c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = external ? (hipStream_t)hip_stream : c->own_stream;
+    if (next == c->stream) return KWS_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->order_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->order_ev, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(next, c->order_ev, 0));
+    if (c->stream_graph) {  // a captured push replays on the stream it was captured for: retire it once it is idle
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        drop_stream_graph(c);
+    }
+    c->stream = next;
     return KWS_OK;
 }
 
@@ -501,6 +511,7 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
         (void)hipFree(d);
         return fail_hip(c, e, "kws_load_dscnn: hipMemcpy");
     }
+    drop_stream_graph(c);  // a captured push holds the old weight pointers by value
     if (c->d_model) (void)hipFree(c->d_model);
     c->d_model = d;
     c->mw.c1_w = d + o_c1w;
@@ -587,8 +598,7 @@ int kws_set_pointwise_math(kws_ctx* c, int math) {
         return fail(c, KWS_EINVAL, "kws_set_pointwise_math: math must be KWS_PW_F32 or KWS_PW_SPLIT_BF16");
     if (math != c->pw_math && c->stream_graph) {  // the captured graph holds the other kernel
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        (void)hipGraphExecDestroy(c->stream_graph);
-        c->stream_graph = nullptr;
+        drop_stream_graph(c);
     }
     c->pw_math = math;
     return KWS_OK;
@@ -638,6 +648,12 @@ static void vad_free(kws_ctx* c) {
     c->d_vad_flags = nullptr;
     c->d_vad_state = nullptr;
     c->vad_on = c->vad_off = 0;
+}
+
+static void drop_stream_graph(kws_ctx* c) {
+    if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
+    c->stream_graph = nullptr;
+    c->graph_key[0] = c->graph_key[1] = c->graph_key[2] = nullptr;
 }
 
 static void stream_free(kws_ctx* c) {
@@ -916,8 +932,10 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
     if (use_graph) {
         // one hipGraph per (hop, logits, label) pointer triple: the two launches replay as one submission
         if (!c->stream_graph || c->graph_key[0] != d_hop || c->graph_key[1] != d_logits || c->graph_key[2] != d_label) {
-            if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
-            c->stream_graph = nullptr;
+            if (c->stream_graph) {  // other buffers than the captured ones: retire the old graph once it is idle
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                drop_stream_graph(c);
+            }
             hipGraph_t g = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             hipError_t e = stream_enqueue(c, d_hop, d_logits, d_label);

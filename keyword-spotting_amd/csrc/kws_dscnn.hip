@@ -363,8 +363,11 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 // MODE: 0 = pointwise GEMM on the VALU (cross-check of the MFMA operand mappings), 1 = f32 MFMA,
 // 4 = split-bf16 MFMA (product path), 2 / 3 = timing ablations of mode 1 (matrix core only / stencil only;
 // wrong results by construction).
+// act4 (diagnostics instantiation only, block 4): global [64][53*9] that receives the block's output, which the product
+// path never stores (it is pooled in registers).
 template <int N, int MODE>
-__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo) {
+__device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo,
+                                            float* __restrict__ act4 = nullptr) {
     using G = Blk<N>;
     constexpr bool MFMA = MODE != 0;
     constexpr bool SPLIT = MODE >= 4;  // input channel of step s: 16(s>>3) + 8*half + (s&7) instead of 2s + half
@@ -582,6 +585,13 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                         psum[0][r] += valid ? relu(acc0[r]) : 0.f;
                         psum[1][r] += valid ? relu(acc1[r]) : 0.f;
                     }
+                    if (act4 && valid) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            act4[row_of(r, half) * G::POUT + pos] = relu(acc0[r]);
+                            act4[(32 + row_of(r, half)) * G::POUT + pos] = relu(acc1[r]);
+                        }
+                    }
                 }
             };
             // this wave's last unit: the A operands are dead, so the next block's are fetched now and the
@@ -623,6 +633,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     if (valid && half == 0) zout[pidx(co, pos, G::SOUT)] = tot;
                 } else {
                     // pool: sum this tile's positions and accumulate into the wave's own scratch row
+                    if (act4 && valid && half == 0) act4[co * G::POUT + pos] = tot;
                     float sum = (valid && half == 0) ? tot : 0.f;
 #pragma unroll
                     for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z3 + pidx(i / Blk<3>::POUT, i % Blk<3>::POUT, Blk<3>::SOUT)];
         a += CH * Blk<3>::POUT;
     }
-    block_phase<4, MODE>(w, lds, tid, wa);
+    block_phase<4, MODE>(w, lds, tid, wa, a ? a + CH : nullptr);  // block 4's output follows the pooled means
     stamp();  // 10
     // The classifier row of lane c (wavefront 0) and the ring bias of channel tid are requested BEFORE the barrier:
     // their L2 round trips pass while the workgroup waits for its slowest wavefront, instead of sitting exposed at
@@ -899,6 +910,9 @@ __global__ void kws_softmax_f32_kernel(const float* __restrict__ logits, int B, 
 
 // Moving average of the last `window` posterior vectors per stream (ring [S][window][C], running sum [S][C]),
 // then argmax of the smoothed vector (first maximum wins).  count = hops smoothed so far, before this one.
+// The running sum is updated incrementally (sum += p - oldest) and REBUILT from the ring every `window` hops (when the
+// write slot wraps to 0), so its float32 rounding error is bounded by one window's worth of updates instead of growing
+// over the life of a stream (10 ms hops = 8.6 M updates a day).
 __global__ void kws_smooth_posteriors_kernel(const float* __restrict__ logits, int S, int C, int window,
                                              float* __restrict__ ring, float* __restrict__ sum, int* __restrict__ count_ptr,
                                              float* __restrict__ smoothed, int32_t* __restrict__ label) {
@@ -927,11 +941,18 @@ __global__ void kws_smooth_posteriors_kernel(const float* __restrict__ logits, i
     const float inv = 1.0f / (float)((count + 1 < window) ? count + 1 : window);
     float best = -1.f;
     int arg = 0;
+    const bool rebuild = count >= window && slot == 0;
     for (int i = 0; i < C; ++i) {
         const float old = count >= window ? r[i] : 0.f;
-        const float a = acc[i] + (p[i] - old);
-        acc[i] = a;
         r[i] = p[i];
+        float a;
+        if (rebuild) {
+            a = 0.f;
+            for (int k = 0; k < window; ++k) a += ring[((size_t)s * window + k) * C + i];
+        } else {
+            a = acc[i] + (p[i] - old);
+        }
+        acc[i] = a;
         const float v = a * inv;
         smoothed[(size_t)s * C + i] = v;
         if (v > best) {

@@ -169,6 +169,14 @@ class StreamingSpotter:
         self.vad_state: Optional[np.ndarray] = None
         torch.cuda.synchronize(self.device)
 
+    def load_model(self, model: DepthwiseSeparableConv) -> None:
+        """Swap the classifier while the streams keep running (their PCM and feature rings are untouched); a captured
+        hipGraph is re-captured on the next push (``kws_load_dscnn`` retires it: it holds the old weights)."""
+        if model.num_classes != self.model.num_classes:
+            raise ModelError(f"the streams were opened for {self.model.num_classes} classes, the new model has {model.num_classes}")
+        self.model = model
+        self._ctx.load_dscnn(model.packed_weights(), model.num_classes)
+
     def push(self, samples) -> Tuple[np.ndarray, np.ndarray]:
         """``int16[n_streams, hop]`` (host array or device tensor) -> (labels int32[S], logits float32[S,C]);
         with ``smooth_window`` > 0 the second array holds the smoothed posteriors and the labels are their argmax."""

@@ -100,6 +100,13 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
         """The 20 ``state_dict`` tensors, in order, as one float32 vector (``kws_load_dscnn`` layout)."""
         return np.concatenate([v.detach().to("cpu", torch.float32).reshape(-1).numpy() for v in self.state_dict().values()])
 
+    def sync_weights(self) -> None:
+        """Force a re-upload of the parameters at the next forward.  The device copy is refreshed automatically when
+        a parameter is replaced or modified through autograd-visible in-place operations (``p.copy_``, ``p.add_``,
+        ``load_state_dict``: they bump ``p._version``); edits made behind torch's back through ``p.data`` (e.g.
+        ``p.data.clamp_()``) do not, and need this call."""
+        self._uploaded = None
+
     def _context(self, device_index: int):
         from kws import _native
 
@@ -192,6 +199,10 @@ class DepthwiseSeparableConvBN(KeywordSpottingModel):
         self._folded_key = key
         return out
 
+    def sync_weights(self) -> None:
+        """Drop the cached fold (needed only after edits through ``.data``, which do not bump ``_version``)."""
+        self._folded_key = None
+
     def forward(self, x: torch.Tensor, return_labels: bool = False):
         return self.fold().forward(x, return_labels)
 
@@ -218,6 +229,11 @@ class CnnTradFpool3(KeywordSpottingModel):
 
     def packed_weights(self) -> np.ndarray:
         return np.concatenate([v.detach().to("cpu", torch.float32).reshape(-1).numpy() for v in self.state_dict().values()])
+
+    def sync_weights(self) -> None:
+        """Force a re-upload at the next forward (needed only after edits through ``p.data``, which do not bump
+        ``p._version``; see ``DepthwiseSeparableConv.sync_weights``)."""
+        self._uploaded = None
 
     def _context(self, device_index: int):
         from kws import _native

@@ -51,6 +51,12 @@ def dscnn_golden():
     return np.load(os.path.join(GOLDEN, "dscnn_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def e2e_golden():
+    """Diverse clips + signal-preserving weights -> logits / labels of the imported reference model (make_golden.py)."""
+    return np.load(os.path.join(GOLDEN, "e2e_golden.npz"))
+
+
 def synth_clips(batch: int, seed: int = 0, kind: str = "uniform") -> np.ndarray:
     """Synthetic int16 [batch,16000] clips of SURVEY.md section 8(d)."""
     rng = np.random.default_rng(seed)

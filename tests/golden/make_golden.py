@@ -9,6 +9,10 @@ Writes (data only -- inputs and expected outputs, no reference source):
                                     framesig(rect) / powspec outputs
   tests/golden/dscnn_golden.npz     seeded state_dicts + inputs -> reference
                                     DepthwiseSeparableConv logits, per-layer probes
+  tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
+                                    reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
+                                    AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
+                                    here), plus two tie cases for the first-maximum rule of torch.max
 
 Reference modules used (imported, never copied):
   kws/libs/speech_features/sigproc.py:14-103   (framesig, magspec, powspec, preemphasis)
@@ -155,6 +159,120 @@ def dscnn_golden():
     print("dscnn_golden.npz written")
 
 
+def diverse_clips() -> "tuple[np.ndarray, list]":
+    """48 int16 clips whose spectra, levels and envelopes differ: the 8 sigproc clips, sines, chirps, uniform and
+    Gaussian noise at several levels, gated noise/tone bursts over a noise floor."""
+    base, base_names = make_clips()
+    rs = np.random.RandomState(5)
+    t = np.arange(N)
+    clips, names = list(base), list(base_names)
+    for f in (200, 440, 1000, 2500, 5000, 7000):
+        names.append(f"sine_{f}Hz_a8000"); clips.append(np.round(8000 * np.sin(2 * np.pi * f * t / 16000.0)).astype(np.int16))
+    for f0, f1 in ((100, 4000), (6000, 300), (50, 7900)):
+        ph = 2 * np.pi * (f0 * t / 16000.0 + (f1 - f0) * t * t / (2.0 * 16000 * 16000))
+        names.append(f"chirp_{f0}_{f1}"); clips.append(np.round(15000 * np.sin(ph)).astype(np.int16))
+    for amp in (32767, 3000, 300, 30):
+        names.append(f"uniform_a{amp}"); clips.append(rs.randint(-amp, amp + 1, size=N).astype(np.int16))
+    for sigma in (9000, 1000, 100, 10):
+        names.append(f"gauss_s{sigma}")
+        clips.append(np.clip(np.round(rs.standard_normal(N) * sigma), -32768, 32767).astype(np.int16))
+    while len(clips) < 48:
+        env = np.zeros(N)
+        a = rs.randint(0, 12000)
+        env[a:a + rs.randint(1000, 4000)] = 1
+        f = rs.uniform(100, 6000)
+        tone = np.sin(2 * np.pi * f * t / 16000.0) * rs.choice([0, 1000, 6000])
+        x = (rs.standard_normal(N) * rs.choice([30, 300, 3000, 9000]) + tone) * env + rs.standard_normal(N) * rs.choice([0, 2, 20])
+        names.append(f"burst_{len(clips)}"); clips.append(np.clip(np.round(x), -32768, 32767).astype(np.int16))
+    return np.stack(clips), names
+
+
+def he_state(seed: int, in_scale: float = 15.0, fc_std: float = 0.5, bias_std: float = 0.1):
+    """Signal-preserving weights: conv weights N(0, 2/fan_in) (fan_in = in_channels/groups * kh * kw), conv1 also
+    divided by `in_scale` (an input normalisation folded into the first layer: the MFCC maps have RMS ~ 15), biases
+    N(0, 0.1), fc N(0, 0.5).  Activations stay O(1..30) through the net, so the logits depend on the audio."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k, shp in o_dscnn.state_shapes(12).items():
+        if k.endswith("bias"):
+            w = rs.standard_normal(shp) * bias_std
+        elif k.startswith("fc"):
+            w = rs.standard_normal(shp) * fc_std
+        else:
+            w = rs.standard_normal(shp) * np.sqrt(2.0 / int(np.prod(shp[1:])))
+            if k.startswith("conv1"):
+                w = w / in_scale
+        out[k] = torch.from_numpy(w.astype(np.float32))
+    return out
+
+
+def ref_forward_with_layers(st, x):
+    ref = ref_models.DepthwiseSeparableConv(num_classes=12).eval()
+    ref.load_state_dict(st)
+    with torch.no_grad():
+        h = torch.relu(ref.conv1(x)); layers = {"conv1": h}
+        for i, blk in enumerate([ref.dsconv1, ref.dsconv2, ref.dsconv3, ref.dsconv4], 1):
+            d = blk.depthwise(h); layers[f"dsconv{i}.depthwise"] = d
+            h = blk(h); layers[f"dsconv{i}"] = h
+        logits = ref(x)
+        labels = torch.max(logits, 1)[1]                                         # kws/libs/training.py:371
+    return logits, labels, layers
+
+
+def e2e_golden():
+    clips, names = diverse_clips()
+    rs = np.random.RandomState(11)
+    x_rand = torch.from_numpy((3.0 * rs.standard_normal((8, 1, 99, 10))).astype(np.float32))
+    x_mfcc = torch.from_numpy(o_mfcc.collate_pcm16(clips))     # oracle front end (psf tail unpinned), float32 as the loader casts
+    x = torch.cat([x_rand, x_mfcc], 0)
+
+    st = he_state(seed=2)
+    logits0, _, _ = ref_forward_with_layers(st, x_mfcc)
+    # a trained classifier's classes are balanced over its data: centre the logits over the clip set (float32)
+    st["fc.bias"] = (st["fc.bias"] - logits0.mean(0)).float()
+    logits, labels, layers = ref_forward_with_layers(st, x)
+    o_logits, o_layers = o_dscnn.forward(st, x, return_layers=True)
+    np.testing.assert_allclose(o_logits.numpy(), logits.numpy(), rtol=0, atol=2e-6 * float(logits.abs().max()))
+    for name, t in layers.items():
+        np.testing.assert_allclose(o_layers[name].numpy(), t.numpy(), rtol=0, atol=2e-6 * float(t.abs().max()))
+    assert torch.equal(o_dscnn.predict(o_logits), labels)
+    clip_logits, clip_labels = logits[8:], labels[8:]
+    n_classes = len(set(clip_labels.tolist()))
+    spread = float(clip_logits.std(0).mean())
+    top2 = torch.topk(logits, 2, dim=1).values
+    print(f"he: {n_classes} classes over {len(clips)} clips, logit std across clips {spread:.3f}, "
+          f"|logit| max {float(logits.abs().max()):.2f}, min top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.2e}")
+    assert n_classes >= 6 and spread >= 0.1, "the fixture must depend on the audio"
+
+    save = {"clips": clips, "names": np.array(names), "x_rand": x_rand.numpy(),
+            "he.blob": o_dscnn.flatten_state(st), "he.logits": logits.numpy(), "he.label": labels.numpy()}
+    for k, v in probe_layers(layers).items():
+        save[f"he.{k}"] = v
+    save["he.dsconv4.full"] = layers["dsconv4"][PROBE].numpy()                   # block 4 output, ring included
+    save["he.pool"] = torch.nn.functional.adaptive_avg_pool2d(layers["dsconv4"], (1, 1)).reshape(len(x), -1).numpy()
+
+    # ties (torch.max returns the FIRST maximum): (a) every class row identical -> every logit ties -> label 0;
+    # (b) row hi := row lo for the most frequent label lo -> wherever lo wins, hi ties with it and lo must be reported
+    tie_a = {k: v.clone() for k, v in st.items()}
+    tie_a["fc.weight"] = st["fc.weight"][3:4].repeat(12, 1).contiguous()
+    tie_a["fc.bias"] = st["fc.bias"][3:4].repeat(12).contiguous()
+    la, ya, _ = ref_forward_with_layers(tie_a, x)
+    assert bool((la == la[:, :1]).all()) and bool((ya == 0).all())
+    lo = int(torch.bincount(clip_labels, minlength=12)[:11].argmax())
+    hi = 11
+    tie_b = {k: v.clone() for k, v in st.items()}
+    tie_b["fc.weight"][hi] = st["fc.weight"][lo]
+    tie_b["fc.bias"][hi] = st["fc.bias"][lo]
+    lb, yb, _ = ref_forward_with_layers(tie_b, x)
+    assert bool((lb[:, lo] == lb[:, hi]).all()) and int((yb == lo).sum()) >= 3 and not bool((yb == hi).any())
+    save.update({"tie_all.blob": o_dscnn.flatten_state(tie_a), "tie_all.logits": la.numpy(), "tie_all.label": ya.numpy(),
+                 "tie_pair.blob": o_dscnn.flatten_state(tie_b), "tie_pair.logits": lb.numpy(), "tie_pair.label": yb.numpy(),
+                 "tie_pair.lo_hi": np.array([lo, hi])})
+    np.savez_compressed(os.path.join(HERE, "e2e_golden.npz"), **save)
+    print("e2e_golden.npz written; labels:", labels.tolist())
+
+
 if __name__ == "__main__":
     sigproc_golden()
     dscnn_golden()
+    e2e_golden()

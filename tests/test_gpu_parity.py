@@ -52,6 +52,15 @@ def state_from_blob(blob):
     return st
 
 
+def he_model(e2e_golden):
+    """kws.libs.models.DepthwiseSeparableConv holding the golden signal-preserving weights."""
+    from kws.libs.models import DepthwiseSeparableConv
+
+    model = DepthwiseSeparableConv(num_classes=12)
+    model.load_state_dict(state_from_blob(e2e_golden["he.blob"]))
+    return model
+
+
 def gpu_mfcc(ctx, dev, clips):
     wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
     nf, nc = ctx.frontend_shape()
@@ -189,39 +198,85 @@ def split_act(act):
         out[name] = act[:, off:off + 64 * p].reshape(-1, 64, p)
         off += 64 * p
     out["pool"] = act[:, off:off + 64]
+    off += 64
+    out["dsconv4"] = act[:, off:off + 64 * 477].reshape(-1, 64, 477)
     return out
 
 
-@pytest.mark.parametrize("tag", ["n01", "default"])
-@pytest.mark.parametrize("use_mfma", [0, 1, 4])  # VALU cross-check, f32 MFMA, split-bf16 MFMA
-def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, tag, use_mfma):
+LAYER_RTOL = 2e-5  # per-layer gate: max abs error <= LAYER_RTOL * max |reference activation| of that layer (no floor)
+
+
+def golden_case(dscnn_golden, e2e_golden, tag):
+    """(blob, x, reference logits, reference labels) of a golden tag; 'he' = signal-preserving weights on 8 random
+    maps + the oracle MFCC of 48 diverse clips (e2e_golden.npz), 'n01' / 'default' = the round-1 tags."""
+    if tag == "he":
+        g = e2e_golden
+        x = np.concatenate([g["x_rand"], o_mfcc.collate_pcm16(g["clips"])])
+        return g["he.blob"], x, g["he.logits"], g["he.label"]
     g = dscnn_golden
-    blob = g[f"{tag}.blob"]
+    return g[f"{tag}.blob"], g["x"], g[f"{tag}.logits"], g[f"{tag}.label"]
+
+
+@pytest.mark.parametrize("tag", ["he", "n01", "default"])
+@pytest.mark.parametrize("use_mfma", [0, 1, 4])  # VALU cross-check, f32 MFMA, split-bf16 MFMA
+def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, e2e_golden, tag, use_mfma):
+    blob, x_np, ref_logits, ref_label = golden_case(dscnn_golden, e2e_golden, tag)
     ctx.load_dscnn(blob, 12)
-    x = torch.from_numpy(g["x"]).to(dev)
+    x = torch.from_numpy(x_np).to(dev)
     B = x.shape[0]
     logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
     labels = torch.empty((B,), dtype=torch.int32, device=dev)
     act = torch.zeros((B, native.ACT_FLOATS_PER_CLIP), dtype=torch.float32, device=dev)
     ctx.forward_debug_f32(x, logits, labels, act, use_mfma=use_mfma)
     ctx.sync()
-    _, layers = o_dscnn.forward(state_from_blob(blob), torch.from_numpy(g["x"]), return_layers=True)
+    _, layers = o_dscnn.forward(state_from_blob(blob), torch.from_numpy(x_np), return_layers=True)
     got = split_act(act.cpu().numpy())
-    want = {
-        "conv1": layers["conv1"].numpy().reshape(B, 64, -1),
-        "dsconv1": layers["dsconv1"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
-        "dsconv2": layers["dsconv2"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
-        "dsconv3": layers["dsconv3"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1),
-        "pool": layers["pool"].numpy(),
-    }
-    for name in ["conv1", "dsconv1", "dsconv2", "dsconv3", "pool"]:
-        scale = max(1.0, float(np.abs(want[name]).max()))
+    want = {"conv1": layers["conv1"].numpy().reshape(B, 64, -1), "pool": layers["pool"].numpy()}
+    for i in range(1, 5):
+        want[f"dsconv{i}"] = layers[f"dsconv{i}"].numpy()[:, :, 1:-1, 1:-1].reshape(B, 64, -1)
+    for name in ["conv1", "dsconv1", "dsconv2", "dsconv3", "dsconv4", "pool"]:
+        scale = float(np.abs(want[name]).max())
         err = float(np.abs(got[name] - want[name]).max())
-        assert err <= 2e-5 * scale, f"{tag} mfma={use_mfma} layer {name}: max abs err {err} (scale {scale})"
+        assert err <= LAYER_RTOL * scale, f"{tag} mfma={use_mfma} layer {name}: max abs err {err:.3e} (scale {scale:.3e})"
     # against the reference module's own logits (golden), and its labels
-    assert np.abs(logits.cpu().numpy() - g[f"{tag}.logits"]).max() <= TOL
-    if tag == "n01":
-        assert np.array_equal(labels.cpu().numpy(), g[f"{tag}.label"])
+    lg = logits.cpu().numpy()
+    err = float(np.abs(lg - ref_logits).max())
+    assert err <= min(TOL, LAYER_RTOL * max(float(np.abs(ref_logits).max()), 1e-30) * 4), f"{tag}: logits err {err:.3e}"
+    if tag == "he":
+        # the fixture depends on its input: many classes, logits that move from clip to clip -- and the kernel follows
+        assert len(set(ref_label[8:].tolist())) >= 6 and float(ref_logits[8:].std(axis=0).mean()) >= 0.1
+        assert np.array_equal(labels.cpu().numpy(), ref_label)
+    elif tag == "n01":
+        assert np.array_equal(labels.cpu().numpy(), ref_label)
+
+
+@pytest.mark.parametrize("use_mfma", [0, 1, 4])
+def test_argmax_ties_first_maximum_wins(native, ctx, dev, e2e_golden, use_mfma):
+    """torch.max(outputs, 1) returns the first maximum (kws/libs/training.py:371).  tie_all: twelve identical class
+    rows -> every logit ties -> label 0 for every input; tie_pair: row 11 is a copy of row lo -> wherever lo wins the two
+    tie exactly and lo must be reported.  Expected labels come from the reference module itself (make_golden.py)."""
+    g = e2e_golden
+    x = torch.from_numpy(np.concatenate([g["x_rand"], o_mfcc.collate_pcm16(g["clips"])])).to(dev)
+    B = x.shape[0]
+    lo, hi = (int(v) for v in g["tie_pair.lo_hi"])
+    for tag in ("tie_all", "tie_pair"):
+        ctx.load_dscnn(g[f"{tag}.blob"], 12)
+        logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
+        labels = torch.empty((B,), dtype=torch.int32, device=dev)
+        if use_mfma == 4:
+            ctx.forward_f32(x, logits, labels)  # the product instantiation
+        else:
+            act = torch.zeros((B, native.ACT_FLOATS_PER_CLIP), dtype=torch.float32, device=dev)
+            ctx.forward_debug_f32(x, logits, labels, act, use_mfma=use_mfma)
+        ctx.sync()
+        lg, lb = logits.cpu().numpy(), labels.cpu().numpy()
+        assert np.abs(lg - g[f"{tag}.logits"]).max() <= TOL
+        if tag == "tie_all":
+            assert np.all(lg == lg[:, :1]) and np.all(lb == 0)
+        else:
+            assert np.array_equal(lg[:, lo], lg[:, hi])          # identical rows -> bit-identical logits
+            assert np.array_equal(lb, g["tie_pair.label"])
+            assert (lb == lo).sum() >= 3 and not (lb == hi).any()
 
 
 def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
@@ -264,19 +319,45 @@ def test_pointwise_math_settings_agree(native, ctx, dev, dscnn_golden):
 
 
 # ------------------------------------------------------------------------------------------- fused wav -> label
+def assert_labels_match(labels, want_logits, err):
+    """argmax must be identical wherever the reference's top-2 margin exceeds 10x the measured logit error (a closer
+    call may legitimately flip); returns the fraction of clips that were compared."""
+    want_logits = torch.as_tensor(want_logits)
+    top2 = torch.topk(want_logits, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 10.0 * max(err, 1e-7)).numpy()
+    assert np.array_equal(np.asarray(labels)[clear], o_dscnn.predict(want_logits).numpy()[clear])
+    return float(clear.mean())
+
+
+def test_infer_golden_diverse_clips(ctx, dev, e2e_golden):
+    """wav -> label on the 48 diverse golden clips with signal-preserving weights: the expected logits and labels are
+    the imported reference model's (on the oracle's MFCC); they span >= 6 classes and move from clip to clip, so a
+    kernel that ignores its input cannot pass."""
+    g = e2e_golden
+    ctx.load_dscnn(g["he.blob"], 12)
+    logits, labels = gpu_infer(ctx, dev, g["clips"])
+    want, want_label = g["he.logits"][8:], g["he.label"][8:]
+    assert len(set(want_label.tolist())) >= 6 and float(want.std(axis=0).mean()) >= 0.1
+    err = float(np.abs(logits - want).max())
+    assert err <= TOL, f"logits max abs err {err:.3e}"
+    assert np.array_equal(labels, want_label)           # min top-2 margin of the fixture is 4.4e-3 >> TOL
+    # silence vs full-scale noise must differ by far more than the tolerance (round 1's weights: 6e-4)
+    assert np.abs(logits[0] - logits[4]).max() > 0.5
+
+
 @pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
-def test_infer_matches_oracle(ctx, dev, kind, seed):
-    state = o_dscnn.random_state(seed=1, std=0.1)
-    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+def test_infer_matches_oracle(ctx, dev, e2e_golden, kind, seed):
+    blob = e2e_golden["he.blob"]
+    state = state_from_blob(blob)
+    ctx.load_dscnn(blob, 12)
     clips = synth_clips(160, seed, kind)
     logits, labels = gpu_infer(ctx, dev, clips)
     want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips)))
-    err = np.abs(logits - want.numpy()).max()
-    assert err <= TOL, f"logits max abs err {err}"
-    top2 = torch.topk(want, 2, dim=1).values
-    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()  # a tie inside the tolerance may legitimately flip
-    assert np.array_equal(labels[clear], o_dscnn.predict(want).numpy()[clear])
-    assert clear.mean() > 0.95
+    err = float(np.abs(logits - want.numpy()).max())
+    assert err <= TOL, f"logits max abs err {err:.3e}"
+    assert assert_labels_match(labels, want, err) > 0.95
+    if kind == "gauss":  # every 16th clip is silence: its logits differ from the noise clips' by far more than TOL
+        assert np.abs(logits[0] - logits[1]).max() > 0.5
 
 
 def test_infer_requires_model(native, dev):
@@ -294,14 +375,20 @@ def test_infer_requires_model(native, dev):
         c.close()
 
 
-def test_full_batch_properties(ctx, dev):
-    """BASELINE workload size (B = 4096): properties that need no oracle at that size."""
-    state = o_dscnn.random_state(seed=1, std=0.1)
-    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+def test_full_batch_properties(ctx, dev, e2e_golden):
+    """BASELINE workload size (B = 4096): properties that need no oracle at that size.  Signal-preserving weights;
+    the batch mixes full-scale noise, quieter noise at many levels, silence and the diverse golden clips, so the labels
+    spread over the classes."""
+    blob = e2e_golden["he.blob"]
+    state = state_from_blob(blob)
+    ctx.load_dscnn(blob, 12)
     B = 4096
     clips = synth_clips(B, 0, "uniform")
+    gain = np.random.default_rng(3).uniform(0.0, 1.0, B) ** 4          # levels from full scale down to a few LSBs
+    clips[1::2] = np.round(clips[1::2] * gain[1::2, None]).astype(np.int16)
     clips[5] = 0
     clips[777] = 0
+    clips[1000:1048] = e2e_golden["clips"]
     logits, labels = gpu_infer(ctx, dev, clips)
     assert np.isfinite(logits).all() and labels.min() >= 0 and labels.max() < 12
     # argmax consistency (first maximum wins) on the device's own logits
@@ -319,13 +406,16 @@ def test_full_batch_properties(ctx, dev):
     # identical inputs -> identical outputs; a sample of the batch against the oracle
     assert np.array_equal(logits[5], logits[777])
     pick = np.arange(0, B, 64)
-    want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips[pick]))).numpy()
-    assert np.abs(logits[pick] - want).max() <= TOL
+    want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips[pick])))
+    err = float(np.abs(logits[pick] - want.numpy()).max())
+    assert err <= TOL, err
+    assert assert_labels_match(labels[pick], want, err) > 0.9
+    assert np.array_equal(labels[1000:1048], e2e_golden["he.label"][8:])
+    assert len(np.unique(labels)) >= 6 and float(logits.std(axis=0).mean()) >= 0.1
 
 
-def test_batch_of_one_and_ragged_sizes(ctx, dev):
-    state = o_dscnn.random_state(seed=1, std=0.1)
-    ctx.load_dscnn(o_dscnn.flatten_state(state), 12)
+def test_batch_of_one_and_ragged_sizes(ctx, dev, e2e_golden):
+    ctx.load_dscnn(e2e_golden["he.blob"], 12)
     clips = synth_clips(67, 5)
     full, _ = gpu_infer(ctx, dev, clips)
     for n in (1, 2, 63, 67):
@@ -334,7 +424,7 @@ def test_batch_of_one_and_ragged_sizes(ctx, dev):
 
 
 # ------------------------------------------------------------------------------------------- host mirror of the reference API
-def test_python_surface_end_to_end(dev, tmp_path):
+def test_python_surface_end_to_end(dev, tmp_path, e2e_golden):
     import wave
 
     from kws.inference import KeywordSpotter
@@ -351,15 +441,12 @@ def test_python_surface_end_to_end(dev, tmp_path):
     batch = ap.extract_features_batch(torch.from_numpy(clips).to(dev))
     assert tuple(batch.shape) == (4, 1, 99, 10) and batch.dtype == torch.float32
     # model with the reference's state_dict layout
-    torch.manual_seed(3)
-    model = DepthwiseSeparableConv(num_classes=12)
-    with torch.no_grad():
-        for p in model.parameters():
-            p.copy_(torch.randn_like(p) * 0.1)
+    model = he_model(e2e_golden)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     logits = model(batch)
     want = o_dscnn.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips)))
     assert float((logits.cpu() - want).abs().max()) <= TOL
+    assert float(want.std(dim=0).mean()) >= 0.1  # the four clips give different logits
     # save / load round trip, then wav files -> words
     path = tmp_path / "model.pth"
     model.save(str(path))
@@ -379,12 +466,12 @@ def test_python_surface_end_to_end(dev, tmp_path):
     assert all(word == spotter.words[idx] for idx, word in got)
 
 
-def test_own_stream_and_profiling_counters(native, dev):
+def test_own_stream_and_profiling_counters(native, dev, e2e_golden):
     """A context on its own (non-blocking) stream: explicit syncs order it against torch; the per-kernel
     event timers count one launch per kernel per call."""
     c = native.Context(0)
     try:
-        c.load_dscnn(o_dscnn.flatten_state(o_dscnn.random_state(seed=1)), 12)
+        c.load_dscnn(e2e_golden["he.blob"], 12)
         clips = synth_clips(32, 8)
         wav = torch.from_numpy(clips).to(dev)
         logits = torch.empty((32, 12), dtype=torch.float32, device=dev)
@@ -401,7 +488,7 @@ def test_own_stream_and_profiling_counters(native, dev):
         c.sync()
         ref = make_ctx(native)
         try:
-            ref.load_dscnn(o_dscnn.flatten_state(o_dscnn.random_state(seed=1)), 12)
+            ref.load_dscnn(e2e_golden["he.blob"], 12)
             l2, _ = gpu_infer(ref, dev, clips)
         finally:
             ref.close()
@@ -447,20 +534,18 @@ def test_augment_matches_numpy_bit_exact(ctx, dev):
 
 # ------------------------------------------------------------------------------------------- streaming
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_streaming_frames_and_labels(native, dev, use_graph):
+def test_streaming_frames_and_labels(native, dev, e2e_golden, use_graph):
     from kws.inference import StreamingSpotter
     from kws.libs.models import DepthwiseSeparableConv
 
     S, hops = 5, 112                     # odd stream count: the last wavefront carries a single stream
-    torch.manual_seed(5)
-    model = DepthwiseSeparableConv(12)
-    with torch.no_grad():
-        for prm in model.parameters():
-            prm.copy_(torch.randn_like(prm) * 0.1)
+    model = he_model(e2e_golden)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     rng = np.random.default_rng(31)
     pcm = rng.integers(-20000, 20000, size=(S, hops * 160), dtype=np.int16)
     pcm[1, : 40 * 160] = 0              # a stream that starts with digital silence
+    pcm[2] = (pcm[2] * np.linspace(0.001, 1.0, hops * 160)).astype(np.int16)   # a stream that fades in
+    pcm[3] = np.round(9000 * np.sin(2 * np.pi * 700 * np.arange(hops * 160) / 16000.0)).astype(np.int16)  # a tone
     sp = StreamingSpotter(S, model, use_graph=use_graph)
     try:
         checks = {2, 3, 50, 99, 100, 101, hops - 1}
@@ -482,26 +567,75 @@ def test_streaming_frames_and_labels(native, dev, use_graph):
                         want[s, i] = allf[f]
             assert np.abs(feats - want).max() <= TOL, f"hop {t}"
             ref = o_dscnn.forward(state, torch.from_numpy(want)[:, None])
-            assert np.abs(logits - ref.numpy()).max() <= TOL, f"hop {t}"
-            top2 = torch.topk(ref, 2, dim=1).values
-            clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()
-            assert np.array_equal(labels[clear], o_dscnn.predict(ref).numpy()[clear])
+            err = float(np.abs(logits - ref.numpy()).max())
+            assert err <= TOL, f"hop {t}: {err:.3e}"
+            assert_labels_match(labels, ref, err)
+            assert float(ref.std(dim=0).mean()) >= 0.1, "the streams' logits must differ"
     finally:
         sp.close()
 
 
-def test_host_ingest_double_buffered(dev):
+def test_streaming_graph_survives_a_weight_reload(dev, e2e_golden):
+    """A captured push holds the weight pointers by value: after kws_load_dscnn (StreamingSpotter.load_model) the next
+    push must classify with the NEW weights (the graph is re-captured), eager and replayed alike; the feature ring is
+    untouched by the reload."""
+    from kws.inference import StreamingSpotter
+
+    S, hops = 4, 104
+    first = he_model(e2e_golden)
+    second = he_model(e2e_golden)
+    with torch.no_grad():
+        second.fc.weight.copy_(torch.flip(second.fc.weight, dims=[0]))      # a visibly different classifier
+        second.fc.bias.copy_(torch.flip(second.fc.bias, dims=[0]))
+        second.dsconv2.pointwise.weight.mul_(0.5)
+    state2 = {k: v.clone() for k, v in second.state_dict().items()}
+    pcm = np.random.default_rng(41).integers(-20000, 20000, size=(S, hops * 160), dtype=np.int16)
+    pcm[1] //= 50
+    sp = StreamingSpotter(S, first, use_graph=True)
+    try:
+        for t in range(hops - 2):
+            sp.push(pcm[:, t * 160:(t + 1) * 160])
+        _, before = sp.push(pcm[:, (hops - 2) * 160:(hops - 1) * 160])
+        sp.load_model(second)
+        _, after = sp.push(pcm[:, (hops - 1) * 160:])
+        feats, pushed = sp.features()
+        assert pushed == hops
+        want = o_dscnn.forward(state2, torch.from_numpy(feats)[:, None]).numpy()
+        assert np.abs(after - want).max() <= TOL
+        assert np.abs(after - before).max() > 0.1          # the old weights would have given `before`-like logits
+    finally:
+        sp.close()
+
+
+def test_trainer_checkpoint_loads(dev, tmp_path, e2e_golden):
+    """KeywordSpottingModel.load accepts the trainer's checkpoint dict ({"model_state_dict": ...},
+    kws/libs/training.py:199-216) as well as a bare state_dict (train.py:77); an edit through .data needs
+    sync_weights()."""
+    from kws.libs.models import DepthwiseSeparableConv
+
+    g = e2e_golden
+    src = he_model(g)
+    ckpt = tmp_path / "best_model.pth"
+    torch.save({"model_state_dict": src.state_dict(), "epoch": 3, "metrics": {"val_acc": 0.5}}, str(ckpt))
+    m = DepthwiseSeparableConv(12)
+    m.load(str(ckpt), device=torch.device("cpu"))
+    x = torch.from_numpy(np.concatenate([g["x_rand"], o_mfcc.collate_pcm16(g["clips"][:8])])).to(dev)
+    logits, labels = m.forward(x, return_labels=True)
+    assert np.abs(logits.cpu().numpy() - g["he.logits"][:16]).max() <= TOL
+    assert np.array_equal(labels.cpu().numpy(), g["he.label"][:16])
+    m.fc.bias.data.add_(1.0)                       # behind torch's back: _version unchanged
+    m.sync_weights()
+    assert np.abs(m.forward(x).cpu().numpy() - (g["he.logits"][:16] + 1.0)).max() <= TOL
+
+
+def test_host_ingest_double_buffered(dev, e2e_golden):
     """KeywordSpotter.infer_batches (pinned staging, H2D on a copy stream overlapped with compute) returns, batch
     by batch and in order, exactly what the device-resident fused call returns -- ragged batch sizes, numpy and
     pre-pinned inputs."""
     from kws.inference import KeywordSpotter
     from kws.libs.models import DepthwiseSeparableConv
 
-    torch.manual_seed(3)
-    model = DepthwiseSeparableConv(12)
-    with torch.no_grad():
-        for prm in model.parameters():
-            prm.normal_(0.0, 0.1)
+    model = he_model(e2e_golden)
     sp = KeywordSpotter(model)
     batches = [synth_clips(b, seed, "uniform") for seed, b in enumerate([64, 7, 130, 1, 64])]
     mixed = [b if i % 2 == 0 else torch.from_numpy(b).pin_memory() for i, b in enumerate(batches)]
@@ -529,22 +663,21 @@ def test_mfcc_batch_beyond_grid_limit(ctx, dev):
 
 
 # ------------------------------------------------------------------------------ model zoo / posteriors (section 8 f-4)
-def test_batchnorm_variant_folds_into_the_fused_kernel(dev):
+def test_batchnorm_variant_folds_into_the_fused_kernel(dev, e2e_golden):
     """DepthwiseSeparableConvBN (build-defined: inference BatchNorm after every convolution) equals its own
     unfolded torch-CPU definition (oracle.dscnn.forward_bn) within the logit tolerance, identical argmax."""
     from kws.libs.models import DepthwiseSeparableConvBN
 
     torch.manual_seed(5)
     m = DepthwiseSeparableConvBN(12)
+    m.plain.load_state_dict(state_from_blob(e2e_golden["he.blob"]))   # signal-preserving weights, MFCC-scaled inputs
     with torch.no_grad():
-        for prm in m.plain.parameters():
-            prm.normal_(0.0, 0.1)
         for bn in [m.bn_conv1, *m.bn_dw, *m.bn_pw]:
             bn.weight.uniform_(0.5, 1.5)
             bn.bias.normal_(0.0, 0.2)
             bn.running_mean.normal_(0.0, 0.3)
             bn.running_var.uniform_(0.3, 2.0)
-    x = torch.randn(33, 1, 99, 10)
+    x = torch.from_numpy(o_mfcc.collate_pcm16(e2e_golden["clips"][:33]))
     state = {k: v.detach().clone() for k, v in m.plain.state_dict().items()}
     names = ["conv1"] + [f"dw{i}" for i in range(1, 5)] + [f"pw{i}" for i in range(1, 5)]
     mods = [m.bn_conv1] + list(m.bn_dw) + list(m.bn_pw)
@@ -553,9 +686,8 @@ def test_batchnorm_variant_folds_into_the_fused_kernel(dev):
     logits, labels = m.forward(x.to(dev), return_labels=True)
     err = (logits.cpu() - want).abs().max().item()
     assert err <= TOL, err
-    top2 = torch.topk(want, 2, dim=1).values
-    clear = ((top2[:, 0] - top2[:, 1]) > 2 * TOL).numpy()
-    assert np.array_equal(labels.cpu().numpy()[clear], want.argmax(dim=1).numpy()[clear])
+    assert float(want.std(dim=0).mean()) >= 0.1 and len(set(want.argmax(dim=1).tolist())) >= 3
+    assert_labels_match(labels.cpu().numpy(), want, err)
     # the folded model is cached until a statistic changes
     assert m.fold() is m.fold()
     with torch.no_grad():
@@ -565,7 +697,7 @@ def test_batchnorm_variant_folds_into_the_fused_kernel(dev):
     assert (logits2.cpu() - logits.cpu()).abs().max().item() > 1e-3
 
 
-def test_softmax_and_streaming_posterior_smoothing(native, dev):
+def test_softmax_and_streaming_posterior_smoothing(native, dev, e2e_golden):
     from kws.inference import StreamingSpotter
     from kws.libs.models import DepthwiseSeparableConv
 
@@ -582,11 +714,7 @@ def test_softmax_and_streaming_posterior_smoothing(native, dev):
     c.close()
 
     # streaming: smoothed posteriors = mean of the softmax of the last W hops' logits (fewer at the start)
-    torch.manual_seed(9)
-    model = DepthwiseSeparableConv(12)
-    with torch.no_grad():
-        for prm in model.parameters():
-            prm.normal_(0.0, 0.1)
+    model = he_model(e2e_golden)
     S, W, hops = 5, 4, 11
     raw = StreamingSpotter(S, model)
     smo = StreamingSpotter(S, model, smooth_window=W)

@@ -166,6 +166,60 @@ def test_dscnn_matches_reference(dscnn_golden, tag):
         np.testing.assert_allclose(a[probe][:, :, :, 1], g[f"{tag}.{name}.col1"], atol=tol)
 
 
+def _state_of(blob):
+    state, off = {}, 0
+    for k, shp in o_dscnn.state_shapes(12).items():
+        n = int(np.prod(shp))
+        state[k] = torch.from_numpy(blob[off:off + n].reshape(shp).copy())
+        off += n
+    return state
+
+
+def test_dscnn_matches_reference_on_signal_preserving_weights(e2e_golden):
+    """The 'he' tag: weights that carry the input to the logits, 8 random maps + the oracle MFCC of 48 diverse clips.
+    Expected values are the imported reference module's; gates are RELATIVE to each tensor's scale.  The fixture itself
+    is checked for power: >= 6 classes, logits that move from clip to clip, silence far from noise."""
+    g = e2e_golden
+    x = torch.from_numpy(np.concatenate([g["x_rand"], o.collate_pcm16(g["clips"])]))
+    logits, layers = o_dscnn.forward(_state_of(g["he.blob"]), x, return_layers=True)
+    ref = g["he.logits"]
+    assert np.abs(logits.numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert np.array_equal(o_dscnn.predict(logits).numpy(), g["he.label"])
+    assert len(set(g["he.label"][8:].tolist())) >= 6 and ref[8:].std(axis=0).mean() >= 0.1
+    assert np.abs(ref[8] - ref[12]).max() > 0.5           # zeros vs full-range uniform noise
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    assert (top2[:, 1] - top2[:, 0]).min() > 1e-3          # no near-tie in the fixture: every label is decidable
+    probe = [0, 4]
+    for name, t in layers.items():
+        a = t.numpy()
+        if a.ndim != 4:
+            continue
+        tol = 2e-6 * float(np.abs(a).max())
+        np.testing.assert_allclose(a.mean(axis=(2, 3)), g[f"he.{name}.chan_mean"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, :3, :3], g[f"he.{name}.corner"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, a.shape[2] // 2, :], g[f"he.{name}.row_mid"], atol=tol)
+        np.testing.assert_allclose(a[probe][:, :, :, 1], g[f"he.{name}.col1"], atol=tol)
+    d4 = layers["dsconv4"].numpy()
+    np.testing.assert_allclose(d4[probe], g["he.dsconv4.full"], atol=2e-6 * float(np.abs(d4).max()))
+    np.testing.assert_allclose(layers["pool"].numpy(), g["he.pool"], atol=2e-6 * float(np.abs(g["he.pool"]).max()))
+
+
+def test_argmax_ties_follow_torch_max(e2e_golden):
+    """First maximum wins (kws/libs/training.py:371): the oracle's predict() on the two tie fixtures gives the labels
+    the reference module's torch.max gave."""
+    g = e2e_golden
+    x = torch.from_numpy(np.concatenate([g["x_rand"], o.collate_pcm16(g["clips"])]))
+    lo, hi = (int(v) for v in g["tie_pair.lo_hi"])
+    for tag in ("tie_all", "tie_pair"):
+        logits = o_dscnn.forward(_state_of(g[f"{tag}.blob"]), x)
+        assert np.abs(logits.numpy() - g[f"{tag}.logits"]).max() <= 2e-6 * np.abs(g[f"{tag}.logits"]).max()
+        # decide on the reference's own logits, so the tie is exact whatever this host's summation order is
+        assert np.array_equal(o_dscnn.predict(torch.from_numpy(g[f"{tag}.logits"])).numpy(), g[f"{tag}.label"])
+    assert np.all(g["tie_all.label"] == 0)
+    assert np.array_equal(g["tie_pair.logits"][:, lo], g["tie_pair.logits"][:, hi])
+    assert (g["tie_pair.label"] == lo).sum() >= 3 and not (g["tie_pair.label"] == hi).any()
+
+
 def test_dscnn_shapes_and_relu_bias_ring():
     st = o_dscnn.random_state(seed=3)
     x = torch.randn(2, 1, 99, 10)
