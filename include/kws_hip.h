@@ -225,8 +225,9 @@ int kws_spec512_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int fra
 
 /* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
  * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
- * launch count per kernel id since the last kws_prof_reset. */
-enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_COUNT = 4 };
+ * launch count per kernel id since the last kws_prof_reset.  The two kernels of an eager kws_stream_push_i16 are timed
+ * too (KWS_K_STREAM_FRAME, KWS_K_DSCNN); a push replayed as a hipGraph is not (events cannot bracket a node). */
+enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_STREAM_FRAME = 4, KWS_K_COUNT = 5 };
 int kws_prof_enable(kws_ctx* ctx, int on);
 int kws_prof_reset(kws_ctx* ctx);
 int kws_prof_read(kws_ctx* ctx, int kernel_id, double* total_ms, int* launches);

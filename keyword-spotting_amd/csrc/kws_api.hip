@@ -11,7 +11,7 @@
 namespace kws {
 
 const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel",
-                                               "kws_cnntrad_dense_kernel"};
+                                               "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel"};
 
 // ------------------------------------------------------------------------------------------------
 // Host tables (double precision, then rounded once to float32).
@@ -910,12 +910,25 @@ int kws_stream_close(kws_ctx* c) {
     return KWS_OK;
 }
 
-static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label) {
-    hipError_t e = launch_stream_frame(c->stream, c->fp, c->ft, d_hop, c->n_streams, c->d_pcm_ring, c->ring_len,
-                                       c->d_feat_ring, c->d_hops);
+// timed: bracket the two launches with profiling events (eager pushes only; never inside a stream capture)
+static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label, bool timed) {
+    hipError_t e;
+    {
+        const bool was = c->prof;
+        c->prof = was && timed;
+        ProfScope ps(c, KWS_K_STREAM_FRAME);
+        c->prof = was;
+        e = launch_stream_frame(c->stream, c->fp, c->ft, d_hop, c->n_streams, c->d_pcm_ring, c->ring_len, c->d_feat_ring,
+                                c->d_hops);
+    }
     if (e != hipSuccess) return e;
-    if (d_logits)
+    if (d_logits) {
+        const bool was = c->prof;
+        c->prof = was && timed;
+        ProfScope ps(c, KWS_K_DSCNN);
+        c->prof = was;
         e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, c->pw_math, nullptr, c->d_hops);
+    }
     return e;
 }
 
@@ -938,7 +951,7 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
             }
             hipGraph_t g = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            hipError_t e = stream_enqueue(c, d_hop, d_logits, d_label);
+            hipError_t e = stream_enqueue(c, d_hop, d_logits, d_label, false);
             hipError_t e2 = hipStreamEndCapture(c->stream, &g);
             if (e != hipSuccess || e2 != hipSuccess || !g) return fail_hip(c, e != hipSuccess ? e : e2, "kws_stream_push_i16: graph capture");
             e = hipGraphInstantiate(&c->stream_graph, g, nullptr, nullptr, 0);
@@ -951,7 +964,7 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
         HIP_TRY(c, hipGraphLaunch(c->stream_graph, c->stream));
         return KWS_OK;
     }
-    HIP_TRY(c, stream_enqueue(c, d_hop, d_logits, d_label));
+    HIP_TRY(c, stream_enqueue(c, d_hop, d_logits, d_label, true));
     return KWS_OK;
 }
 

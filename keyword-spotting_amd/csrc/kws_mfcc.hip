@@ -207,6 +207,37 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
     b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
 }
 
+
+// Level equalisation of a packed frame pair.  The two real frames share one complex transform, so every float32
+// rounding error of the transform is relative to the LARGER frame: a quiet frame packed with a loud one (a speech
+// onset, two microphones at different gains) would get the loud frame's rounding noise, -140 dB below the LOUD frame,
+// in its own spectrum -- measured 2e-2 in the cepstra of the frame before a burst.  Both frames are therefore scaled
+// to energies in [1, 4) by exact powers of two before the transform, and the powers are scaled back (again exactly)
+// when they are formed: a frame's error is then relative to its own level whatever its partner is, and a pair whose
+// frames already have the same exponent gives bit-identical results to the unscaled transform.
+// Returns the factors the POWERS must be multiplied by: 2^(2 s_a), 2^(2 s_b) where the frames were multiplied by 2^-s.
+struct PairLevel {
+    float pow_a, pow_b;
+};
+__device__ __forceinline__ PairLevel equalise_levels(cf (&v)[8]) {
+    cf e2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(e2) : "v"(v[i]));
+    float ea = e2.x, eb = e2.y;
+    wave_sum2(ea, eb);  // wave-uniform
+    auto shift_of = [](float e) -> int {
+        const int ex = (int)((__builtin_bit_cast(uint32_t, e) >> 23) & 0xffu);  // biased exponent of the energy
+        if (ex == 0 || ex == 255) return 0;                                        // zero / denormal / non-finite: leave as is
+        const int s = (ex - 127) >> 1;                                             // floor(log2(energy) / 2)
+        return s < -30 ? -30 : (s > 30 ? 30 : s);                                  // 2^(+-60) on the powers stays far from the f32 limits
+    };
+    const int sa = shift_of(ea), sb = shift_of(eb);
+    const cf down = {__builtin_bit_cast(float, (uint32_t)(127 - sa) << 23), __builtin_bit_cast(float, (uint32_t)(127 - sb) << 23)};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * down;
+    return {__builtin_bit_cast(float, (uint32_t)(127 + 2 * sa) << 23), __builtin_bit_cast(float, (uint32_t)(127 + 2 * sb) << 23)};
+}
+
 // First-pass twiddles of this lane, W512^(lane*i).
 __device__ __forceinline__ void load_twiddles(const float2* __restrict__ tw, int lane, cf (&t1)[8]) {
 #pragma unroll
@@ -232,8 +263,10 @@ __device__ __forceinline__ void fill_tw2(const float2* __restrict__ tw, cf* tw2,
 // partner frame's float32 rounding noise (-140 dB), so it is forced.
 // pslot[j]: power-buffer slot of bin lane + 64j (the MFCC path stores the bins grouped by mel chunk; the
 // spectrum operators pass the identity); slot256: where bin 256 goes, or -1 to drop it.
+// lv: the exact power-of-two factors that undo equalise_levels (applied to the powers before any square root).
 __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* pbuf, int lane, int power, bool nza,
-                                            bool nzb, const int (&pslot)[4], int slot256, float& ea, float& eb) {
+                                            bool nzb, const int (&pslot)[4], int slot256, const PairLevel& lv, float& ea,
+                                            float& eb) {
     const int k1 = lane >> 3, q = lane & 7;
 #pragma unroll
     for (int d = 0; d < 8; ++d) zbuf[zswz(k1 + 8 * q + 64 * d)] = v[d];
@@ -247,13 +280,14 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
     }
     wave_lds_order();
     const float scale = power ? (1.0f / (4.0f * NFFT)) : 0.25f;
+    const float scale_a = scale * lv.pow_a, scale_b = scale * lv.pow_b;  // products of powers of two: exact
     float pa[4], pb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float ar = z[j].x + w[j].x, ai = z[j].y - w[j].y;  // 2*A
         const float br = z[j].y + w[j].y, bi = z[j].x - w[j].x;  // 2*B (up to a unit factor)
-        pa[j] = fmaf(ar, ar, ai * ai) * scale;
-        pb[j] = fmaf(br, br, bi * bi) * scale;
+        pa[j] = fmaf(ar, ar, ai * ai) * scale_a;
+        pb[j] = fmaf(br, br, bi * bi) * scale_b;
         if (!power) {
             pa[j] = sqrtf(pa[j]);
             pb[j] = sqrtf(pb[j]);
@@ -277,7 +311,7 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
     }
     // bin 256 = Z[256] lives in lane 0, register 4 (k1 = 0, q = 0, d = 4); it is its own mirror image
     if (lane == 0) {
-        float pa = (2.f * v[4].x) * (2.f * v[4].x) * scale, pb = (2.f * v[4].y) * (2.f * v[4].y) * scale;
+        float pa = (2.f * v[4].x) * (2.f * v[4].x) * scale_a, pb = (2.f * v[4].y) * (2.f * v[4].y) * scale_b;
         if (!power) {
             pa = sqrtf(pa);
             pb = sqrtf(pb);
@@ -384,10 +418,11 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     const cf* tw2 = sc.tw2;
     const uint32_t gth = ml.gth;
     const int nfp = sc.nfp;
+    const PairLevel lv = equalise_levels(v);
     fft512(v, xbuf, t1, tw2, lane);
 
     float ea, eb;
-    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, ea, eb);
+    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb);
     wave_sum2(ea, eb);
 
     // sparse mel: this lane's chunk of <= 8 bins is one contiguous 64-byte run of the power buffer (four
@@ -653,10 +688,11 @@ __global__ __launch_bounds__(64) void kws_spec512_f32_kernel(FrontendTables t, c
     }
     nza = __any(nza);
     nzb = __any(nzb);
+    const PairLevel lv = equalise_levels(v);
     fft512(v, xbuf, t1, tw2, lane);
     float ea, eb;
     const int ident[4] = {lane, lane + 64, lane + 128, lane + 192};
-    split_power(v, xbuf, pbuf, lane, power, nza, nzb, ident, 256, ea, eb);
+    split_power(v, xbuf, pbuf, lane, power, nza, nzb, ident, 256, lv, ea, eb);
     for (int k = lane; k < NBINS; k += 64) {
         const float2 pw = pbuf[k];
         spec[(size_t)fa * NBINS + k] = pw.x;

@@ -19,7 +19,7 @@ from kws.common.errors import AudioProcessingError, KWSError, ModelError
 LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE = 0, 1, 2, 3
+KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME = 0, 1, 2, 3, 4
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64 + 64 * 477  # KWS_ACT_FLOATS_PER_CLIP
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
 PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16 (default): exact three-way bf16 split, six bf16 MFMAs per f32 product

@@ -33,10 +33,39 @@ def test_two_rank_gloo_run():
     assert out["ok"] and out["world"] == 2 and out["shards"] == [[0, 5], [5, 10]]
 
 
+@pytest.mark.parametrize("extra,scaling,shards", [([], "weak", [16, 16]), (["--total-batch", "25"], "strong", [13, 12])])
+def test_bench_launches_its_own_ranks(extra, scaling, shards):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent starts two child ranks itself
+    (rendezvous on 127.0.0.1, a free port), relays rank 0's single JSON line and exits 0.  Rehearsed on CPU with gloo
+    (--selftest-cpu: no kernel runs; the line says so)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "16", "--selftest-cpu"] + extra
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["selftest"] and out["n_gpus"] == 2 and out["scaling"] == scaling and out["shards"] == shards
+    assert len(out["per_rank_clips_per_s"]) == 2 and out["max_over_ranks_s"] > 0
+    assert out["value"] == pytest.approx(sum(shards) * 3 / out["max_over_ranks_s"])
+
+
+def test_bench_refuses_a_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--selftest-cpu"],
+                          env=env, capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0 and "WORLD_SIZE=3" in (proc.stdout + proc.stderr)
+
+
 def test_weights_and_clips_are_seeded():
     import numpy as np
 
     assert bench.synth_weights().shape == (26444,)
+    assert bench.signal_preserving_weights().shape == (26444,)
+    blob, golden = bench.bench_weights()
+    assert blob.shape == (26444,) and golden is not None and np.array_equal(blob, golden["he.blob"])
     assert np.array_equal(bench.synth_clips(3, 5), bench.synth_clips(3, 5))
     assert bench.synth_clips(2, 0).dtype == np.int16
 
