@@ -437,6 +437,10 @@ def test_full_batch_properties(ctx, dev, e2e_golden):
     perm = np.random.default_rng(1).permutation(B)
     lp, _ = gpu_infer(ctx, dev, clips[perm])
     assert np.array_equal(lp, logits[perm])
+    # BASELINE configs[3]'s shard size (8192 over 8 GPUs = 1024 clips) and a single clip: the same bits as inside the batch
+    for lo, n in ((0, 1024), (3072, 1024), (4095, 1), (0, 1)):
+        lpart, ypart = gpu_infer(ctx, dev, clips[lo:lo + n])
+        assert np.array_equal(lpart, logits[lo:lo + n]) and np.array_equal(ypart, labels[lo:lo + n])
     # identical inputs -> identical outputs; a sample of the batch against the oracle
     assert np.array_equal(logits[5], logits[777])
     pick = np.arange(0, B, 64)
@@ -864,3 +868,86 @@ def test_streaming_energy_endpointer(dev):
         assert want_events[1][0][1] == 1 and want_events[1][1][1] == 2
     finally:
         sp.close()
+
+
+# ------------------------------------------------------------------------------ full-size runs of the other BASELINE configs
+def test_cnn_trad_fused_full_batch_properties(dev):
+    """BASELINE configs[2] read literally at its full size (B = 4096, MFCC + cnn-trad-fpool3 fused): finite, deterministic,
+    permutation-invariant, a sub-batch gives the same bits, every 64th clip against the model's CPU definition."""
+    from kws.libs.models import CnnTradFpool3
+    from oracle import cnn_trad as o_ct
+
+    state = o_ct.random_state(seed=6)
+    m = CnnTradFpool3(12)
+    m.load_state_dict(state)
+    B = 4096
+    clips = synth_clips(B, 21, "uniform")
+    gain = np.random.default_rng(22).uniform(0.0, 1.0, B) ** 4
+    clips[1::2] = np.round(clips[1::2] * gain[1::2, None]).astype(np.int16)
+    clips[9] = 0
+    wav = torch.from_numpy(clips).to(dev)
+    logits, labels = m.infer_pcm16(wav)
+    lg, lb = logits.cpu().numpy(), labels.cpu().numpy()
+    assert np.isfinite(lg).all() and lb.min() >= 0 and lb.max() < 12
+    assert np.array_equal(lb, np.argmax(lg, axis=1).astype(np.int32))
+    l2, y2 = m.infer_pcm16(wav)
+    assert torch.equal(l2, logits) and torch.equal(y2, labels)
+    perm = torch.from_numpy(np.random.default_rng(23).permutation(B)).to(dev)
+    lp, _ = m.infer_pcm16(wav[perm].contiguous())
+    assert torch.equal(lp, logits[perm])
+    ls, _ = m.infer_pcm16(wav[1000:1021].contiguous())          # 21 clips: not a multiple of the dense kernel's 16
+    assert torch.equal(ls, logits[1000:1021])
+    pick = np.arange(0, B, 64)
+    want = o_ct.forward(state, torch.from_numpy(o_mfcc.collate_pcm16(clips[pick])))
+    scale = max(1.0, float(want.abs().max()))
+    err = float(np.abs(lg[pick] - want.numpy()).max())
+    assert err <= TOL * scale, (err, scale)
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = ((top2[:, 0] - top2[:, 1]) > 10 * max(err, 1e-7)).numpy()
+    assert np.array_equal(lb[pick][clear], want.argmax(dim=1).numpy()[clear]) and clear.mean() > 0.8
+    assert float(want.std(dim=0).mean()) > 1e-3 * scale         # the logits move with the input
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_streaming_full_size_64_and_257_streams(dev, e2e_golden, use_graph):
+    """BASELINE configs[4] at its size (64 streams) and at an odd count (257: the last wavefront carries one stream),
+    130 hops: four streams against the oracle at full windows, and independence -- a stream's bits do not depend on how
+    many other streams are open (the two streams of a wavefront share one packed transform, so a stream is compared with
+    the run in which it has the same partner, or none)."""
+    from kws.inference import StreamingSpotter
+
+    model = he_model(e2e_golden)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    hops = 130
+    rng = np.random.default_rng(51)
+    pcm = rng.integers(-20000, 20000, size=(257, hops * 160), dtype=np.int16)
+    level = rng.uniform(0.0, 1.0, 257) ** 3
+    pcm = np.round(pcm * level[:, None]).astype(np.int16)       # every stream at its own level
+    pcm[5] = 0
+    pcm[7] = np.round(6000 * np.sin(2 * np.pi * 1234 * np.arange(hops * 160) / 16000.0)).astype(np.int16)
+    out = {}
+    for S in (257, 64, 1):
+        src = pcm[:S] if S > 1 else pcm[256:257]
+        sp = StreamingSpotter(S, model, use_graph=use_graph)
+        try:
+            for t in range(hops):
+                labels, logits = sp.push(src[:, t * 160:(t + 1) * 160])
+            feats, pushed = sp.features()
+            out[S] = (labels.copy(), logits.copy(), feats.copy())
+            assert pushed == hops
+        finally:
+            sp.close()
+    y257, l257, f257 = out[257]
+    assert np.array_equal(l257[:64], out[64][1]) and np.array_equal(y257[:64], out[64][0]) and np.array_equal(f257[:64], out[64][2])
+    assert np.array_equal(l257[256:], out[1][1]) and np.array_equal(f257[256:], out[1][2])     # the unpaired last stream
+    newest = hops - 3
+    for s in (0, 5, 7, 63, 200, 256):
+        sig = o_mfcc.pcm16_to_float(pcm[s])
+        allf = o_mfcc.mfcc(sig, o_mfcc.FrontendSpec(n_samples=len(sig)))
+        want = allf[newest - 98:newest + 1].astype(np.float32)
+        assert np.abs(f257[s] - want).max() <= TOL, s
+        ref = o_dscnn.forward(state, torch.from_numpy(want)[None, None])
+        err = float(np.abs(l257[s] - ref.numpy()[0]).max())
+        assert err <= TOL, (s, err)
+        assert_labels_match(y257[s:s + 1], ref, err)
+    assert len(np.unique(y257)) >= 3 and float(l257.std(axis=0).mean()) >= 0.1
