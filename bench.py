@@ -765,7 +765,7 @@ def worker(args) -> int:
             }
             lab = labels.cpu().numpy()
             out["labels_seen"] = {"n_classes": int(len(np.unique(lab))), "logit_std_across_clips": float(logits.std(dim=0).mean().item())}
-            if golden is not None:  # the 48 diverse golden clips against the imported reference model's logits (data file)
+            if golden is not None and not args.no_parity:  # the 48 diverse golden clips against the imported reference model's logits (data file)
                 gw = torch.from_numpy(np.ascontiguousarray(golden["clips"])).to(dev)
                 gl = torch.empty((gw.shape[0], NUM_CLASSES), dtype=torch.float32, device=dev)
                 gy = torch.empty((gw.shape[0],), dtype=torch.int32, device=dev)
@@ -824,6 +824,8 @@ def parse_args(argv=None):
                     help="all: at N = 1 the ds-cnn line also measures the other BASELINE configurations under `configs`")
     ap.add_argument("--config-steps", type=int, default=100, help="timed steps of each side configuration")
     ap.add_argument("--stream-hops", type=int, default=340, help="pushes per mode of the streaming configuration (first 40 untimed)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the extra launch on the golden clips after the timed region (profile runs: exact launch counts)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)  # launcher rehearsal on CPU (gloo), tests only
     return ap.parse_args(argv)
 

@@ -107,6 +107,19 @@ int kws_forward_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, i
  * shape of inference(wav) -> label (kws/inference/inference_local.py:67-81), batched. */
 int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label);
 
+/* The same from HOST memory to HOST memory -- what the reference does between the decoded audio and the model input:
+ * DataLoader workers collate batches into pinned memory and the trainer calls inputs.to(device)
+ * (kws/libs/data_loader.py:96-105, train.py:108-121, kws/libs/training.py:286).  h_wav: int16 [B, n_samples] in host
+ * memory (pageable or pinned), h_logits: float32 [B, C], h_label: int32 [B] or NULL, both host.  The batch is cut into
+ * chunks; a pool of host threads packs chunk k+1 into pinned staging while chunk k travels over PCIe on a copy stream,
+ * chunk k-1 runs MFCC + DS-CNN and the results of chunk k-2 return on a second copy stream.  Synchronous: the results
+ * are complete on return.  A pinned h_wav (hipHostMalloc / hipHostRegister / torch pin_memory) is read by the DMA
+ * directly, without the pack stage. */
+int kws_infer_host_i16(kws_ctx* ctx, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label);
+/* Pipeline shape of kws_infer_host_i16: clips per chunk (default 1024), staging slots in flight (default 3, 2..16), host
+ * threads of the pack stage (default min(8, cores/2); negative = pack on the calling thread).  0 keeps a default. */
+int kws_ingest_config(kws_ctx* ctx, int chunk_clips, int n_slots, int pack_threads);
+
 /* Pre-size the internal workspaces for batches up to max_batch (otherwise grown on demand, which
  * allocates and must not happen inside stream capture). */
 int kws_reserve(kws_ctx* ctx, int max_batch);

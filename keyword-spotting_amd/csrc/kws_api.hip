@@ -6,7 +6,7 @@
 #include <cstring>
 #include <new>
 
-#include "kws_internal.h"
+#include "kws_ctx.h"
 
 namespace kws {
 
@@ -145,83 +145,6 @@ void build_twiddle_host(std::vector<float2>& out) {
 
 using namespace kws;
 
-// ------------------------------------------------------------------------------------------------
-struct kws_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t order_ev = nullptr;  // orders the new stream behind the old one in kws_set_stream
-    std::string err;
-
-    // front end
-    int sample_rate = 16000, nfft = NFFT, ceplifter = 22;
-    FrontendParams fp{};
-    bool fe_ready = false;
-    void* d_fe = nullptr;  // one allocation holding all front-end tables
-    FrontendTables ft{};
-
-    // model
-    float* d_model = nullptr;
-    DscnnWeights mw{};
-    bool model_ready = false;
-    int pw_math = KWS_PW_SPLIT_BF16;  // kernel variant of the product entry points
-    // cnn-trad-fpool3
-    void* d_cnntrad = nullptr;
-    CnnTradWeights tw{};
-    bool cnntrad_ready = false;
-    float* d_conv_ws = nullptr;
-    size_t conv_ws_floats = 0;
-
-    // workspace (MFCC features between the two kernels of kws_infer_i16)
-    float* d_feat_ws = nullptr;
-    size_t feat_ws_floats = 0;
-
-    // streaming state (kws_stream_*): per-stream PCM ring, feature ring, hop counter, optional graph
-    int n_streams = 0, ring_len = 0;
-    int16_t* d_pcm_ring = nullptr;
-    float* d_feat_ring = nullptr;
-    int* d_hops = nullptr;
-    hipGraphExec_t stream_graph = nullptr;
-    const void* graph_key[3] = {nullptr, nullptr, nullptr};
-    // posterior smoothing history (kws_stream_smooth_f32): ring [n_streams][window][C], sum [n_streams][C], hop count
-    float* d_post_ring = nullptr;
-    float* d_post_sum = nullptr;
-    int* d_post_count = nullptr;
-    int post_window = 0, post_classes = 0;
-    // energy endpointer (kws_stream_vad_f32): voiced flags [n_streams][off_window], (cursor, triggered) [n_streams][2]
-    unsigned char* d_vad_flags = nullptr;
-    int* d_vad_state = nullptr;
-    int vad_on = 0, vad_off = 0;
-
-    // profiling
-    bool prof = false;
-    struct EvPair {
-        hipEvent_t a, b;
-    };
-    std::vector<EvPair> ev[KWS_K_COUNT];
-    size_t ev_used[KWS_K_COUNT] = {};
-    double ms_total[KWS_K_COUNT] = {};
-    long launches[KWS_K_COUNT] = {};
-};
-
-static thread_local std::string g_create_err;
-
-static int fail(kws_ctx* c, int code, const std::string& msg) {
-    if (c)
-        c->err = msg;
-    else
-        g_create_err = msg;
-    return code;
-}
-static int fail_hip(kws_ctx* c, hipError_t e, const char* what) {
-    return fail(c, KWS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-#define HIP_TRY(c, expr)                                   \
-    do {                                                   \
-        hipError_t _e = (expr);                            \
-        if (_e != hipSuccess) return fail_hip(c, _e, #expr); \
-    } while (0)
-
 static int frames_for(int n_samples, int frame_len, int frame_step) {
     if (n_samples <= frame_len) return 1;
     return 1 + (n_samples - frame_len + frame_step - 1) / frame_step;  // 1 + ceil((n - L)/step)
@@ -307,6 +230,7 @@ void kws_destroy(kws_ctx* c) {
     if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
     if (c->d_feat_ws) (void)hipFree(c->d_feat_ws);
     stream_free_fwd(c);  // rings, hop counter, captured graph, smoothing and endpointer history
+    ingest_free(c);      // staging rings, copy streams, pack threads
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;

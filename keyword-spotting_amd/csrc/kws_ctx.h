@@ -1,0 +1,91 @@
+// The context behind the C ABI (include/kws_hip.h) and the error plumbing shared by the translation units that
+// implement it (kws_api.hip, kws_ingest.hip).
+#pragma once
+#include "kws_internal.h"
+
+namespace kws {
+struct Ingest;  // host-ingest pipeline state (kws_ingest.hip)
+void ingest_free(kws_ctx* c);
+}  // namespace kws
+
+using kws::FrontendParams; using kws::FrontendTables; using kws::DscnnWeights; using kws::CnnTradWeights; using kws::NFFT;
+
+struct kws_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t order_ev = nullptr;  // orders the new stream behind the old one in kws_set_stream
+    std::string err;
+
+    // front end
+    int sample_rate = 16000, nfft = NFFT, ceplifter = 22;
+    FrontendParams fp{};
+    bool fe_ready = false;
+    void* d_fe = nullptr;  // one allocation holding all front-end tables
+    FrontendTables ft{};
+
+    // model
+    float* d_model = nullptr;
+    DscnnWeights mw{};
+    bool model_ready = false;
+    int pw_math = KWS_PW_SPLIT_BF16;  // kernel variant of the product entry points
+    // cnn-trad-fpool3
+    void* d_cnntrad = nullptr;
+    CnnTradWeights tw{};
+    bool cnntrad_ready = false;
+    float* d_conv_ws = nullptr;
+    size_t conv_ws_floats = 0;
+
+    // workspace (MFCC features between the two kernels of kws_infer_i16)
+    float* d_feat_ws = nullptr;
+    size_t feat_ws_floats = 0;
+
+    // streaming state (kws_stream_*): per-stream PCM ring, feature ring, hop counter, optional graph
+    int n_streams = 0, ring_len = 0;
+    int16_t* d_pcm_ring = nullptr;
+    float* d_feat_ring = nullptr;
+    int* d_hops = nullptr;
+    hipGraphExec_t stream_graph = nullptr;
+    const void* graph_key[3] = {nullptr, nullptr, nullptr};
+    // posterior smoothing history (kws_stream_smooth_f32): ring [n_streams][window][C], sum [n_streams][C], hop count
+    float* d_post_ring = nullptr;
+    float* d_post_sum = nullptr;
+    int* d_post_count = nullptr;
+    int post_window = 0, post_classes = 0;
+    // energy endpointer (kws_stream_vad_f32): voiced flags [n_streams][off_window], (cursor, triggered) [n_streams][2]
+    unsigned char* d_vad_flags = nullptr;
+    int* d_vad_state = nullptr;
+    int vad_on = 0, vad_off = 0;
+
+    // host ingest (kws_infer_host_i16): staging rings, copy streams, pack threads -- created on first use
+    kws::Ingest* ingest = nullptr;
+
+    // profiling
+    bool prof = false;
+    struct EvPair {
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> ev[KWS_K_COUNT];
+    size_t ev_used[KWS_K_COUNT] = {};
+    double ms_total[KWS_K_COUNT] = {};
+    long launches[KWS_K_COUNT] = {};
+};
+
+inline thread_local std::string g_create_err;
+
+inline int fail(kws_ctx* c, int code, const std::string& msg) {
+    if (c)
+        c->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+inline int fail_hip(kws_ctx* c, hipError_t e, const char* what) {
+    return fail(c, KWS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, expr)                                   \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return fail_hip(c, _e, #expr); \
+    } while (0)
+

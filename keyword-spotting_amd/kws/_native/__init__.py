@@ -42,6 +42,8 @@ SIGNATURES = {
     "kws_load_dscnn": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
     "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
+    "kws_infer_host_i16": (C.c_int, [_c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "kws_ingest_config": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_int]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
     "kws_set_pointwise_math": (C.c_int, [_c_ctx, C.c_int]),
     "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
@@ -224,6 +226,33 @@ class Context:
             self._lib.kws_infer_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
             ModelError,
         )
+
+    def infer_host_i16(self, wav: np.ndarray, logits: np.ndarray = None, label: np.ndarray = None):
+        """Host ``int16[B,n]`` (numpy array or CPU torch tensor, pageable or pinned) -> host (logits float32[B,C], labels
+        int32[B]) through the library's pack / H2D / compute / D2H pipeline (``kws_infer_host_i16``)."""
+        if self.num_classes is None:
+            raise ModelError("no model loaded (kws_load_dscnn)")
+        if hasattr(wav, "data_ptr"):  # CPU torch tensor (possibly pinned)
+            if wav.is_cuda or wav.dtype.__str__() != "torch.int16" or not wav.is_contiguous() or wav.dim() != 2:
+                raise ModelError("infer_host_i16 expects a contiguous CPU int16 tensor [B, n_samples]")
+            src, B = int(wav.data_ptr()), int(wav.shape[0])
+        else:
+            wav = np.ascontiguousarray(wav, dtype=np.int16)
+            if wav.ndim != 2:
+                raise ModelError("infer_host_i16 expects int16 [B, n_samples]")
+            src, B = wav.ctypes.data, int(wav.shape[0])
+        if logits is None:
+            logits = np.empty((B, self.num_classes), np.float32)
+        if label is None:
+            label = np.empty((B,), np.int32)
+        assert logits.dtype == np.float32 and logits.flags.c_contiguous and logits.shape == (B, self.num_classes)
+        assert label.dtype == np.int32 and label.flags.c_contiguous and label.shape == (B,)
+        self._check(self._lib.kws_infer_host_i16(self._h, C.c_void_p(src), B, C.c_void_p(logits.ctypes.data),
+                                                 C.c_void_p(label.ctypes.data)), ModelError)
+        return logits, label
+
+    def ingest_config(self, chunk_clips: int = 0, n_slots: int = 0, pack_threads: int = 0):
+        self._check(self._lib.kws_ingest_config(self._h, int(chunk_clips), int(n_slots), int(pack_threads)), ModelError)
 
     # -- streaming -------------------------------------------------------------------------------
     def stream_open(self, n_streams: int):

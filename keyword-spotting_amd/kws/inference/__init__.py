@@ -32,76 +32,31 @@ class KeywordSpotter:
         self.model.load(path, device=torch.device("cpu"))  # parameters are packed from the host copy
 
     def infer_pcm16(self, pcm: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """``int16[B,n]`` host array -> (labels int32[B], logits float32[B,C])."""
+        """``int16[B,n]`` host array -> (labels int32[B], logits float32[B,C]) through the library's host-ingest
+        pipeline (``kws_infer_host_i16``: pack into pinned staging, H2D, MFCC + DS-CNN and D2H overlapped chunk by chunk)."""
         clips = fix_length(np.atleast_2d(np.asarray(pcm, dtype=np.int16)), self.config.desired_samples)
-        wav = torch.from_numpy(np.ascontiguousarray(clips)).to(self.device)
-        logits, labels = self.model.infer_pcm16(wav)
-        return labels.cpu().numpy(), logits.cpu().numpy()
+        ctx = self.model._context(self.device.index or 0)
+        logits, labels = ctx.infer_host_i16(np.ascontiguousarray(clips))
+        return labels, logits
 
     def infer_batches(self, batches: Iterable[np.ndarray], max_batch: Optional[int] = None
                       ) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
-        """Host ingest for many batches: every ``int16[B,n]`` host batch is packed into a
-        pinned staging buffer and copied to the GPU on a copy stream while the previous batch runs MFCC + DS-CNN
-        on the compute stream (two staging / device buffer pairs, events between the streams); results come back
-        through pinned buffers.  Yields ``(labels int32[B], logits float32[B,C])`` per batch, in order."""
+        """Host ingest for many batches: every ``int16[B,n]`` host batch (numpy array, or a CPU
+        torch tensor -- a pinned one is read by the DMA directly, without the pack stage) goes through
+        ``kws_infer_host_i16``: chunks of 1024 clips, a pool of host threads packing chunk k+1 into pinned staging while
+        chunk k crosses PCIe on a copy stream, chunk k-1 runs MFCC + DS-CNN and the results of chunk k-2 return on a
+        second copy stream.  Yields ``(labels int32[B], logits float32[B,C])`` per batch, in order.  ``max_batch`` is
+        accepted for compatibility (the staging rings are sized per chunk, not per batch)."""
         n = self.config.desired_samples
-        copy_stream = torch.cuda.Stream(device=self.device)
-        compute_stream = torch.cuda.Stream(device=self.device)
-        slots = []  # per slot: pinned in, device in, pinned logits, pinned labels, copied event, free event, batch size
-
-        def make_slot(cap: int):
-            return {
-                "cap": cap,
-                "h_in": torch.empty((cap, n), dtype=torch.int16).pin_memory(),
-                "d_in": torch.empty((cap, n), dtype=torch.int16, device=self.device),
-                "h_logits": torch.empty((cap, self.model.num_classes), dtype=torch.float32).pin_memory(),
-                "h_labels": torch.empty((cap,), dtype=torch.int32).pin_memory(),
-                "copied": torch.cuda.Event(),
-                "done": torch.cuda.Event(),
-                "b": 0,
-            }
-
-        def launch(slot, batch):
-            if torch.is_tensor(batch) and batch.dtype == torch.int16 and batch.dim() == 2 and batch.shape[1] == n \
-                    and batch.is_pinned():
-                src, b = batch, batch.shape[0]  # the caller already packed into pinned memory: no host copy
-            else:
-                clips = fix_length(np.atleast_2d(np.asarray(batch, dtype=np.int16)), n)
-                b = clips.shape[0]
-                slot["h_in"][:b].numpy()[...] = clips  # pack into pinned memory
-                src = slot["h_in"][:b]
-            slot["b"] = b
-            with torch.cuda.stream(copy_stream):
-                slot["d_in"][:b].copy_(src, non_blocking=True)
-                slot["copied"].record(copy_stream)
-            with torch.cuda.stream(compute_stream):
-                compute_stream.wait_event(slot["copied"])
-                logits, labels = self.model.infer_pcm16(slot["d_in"][:b])
-                slot["h_logits"][:b].copy_(logits, non_blocking=True)
-                slot["h_labels"][:b].copy_(labels, non_blocking=True)
-                slot["done"].record(compute_stream)
-
-        def collect(slot):
-            slot["done"].synchronize()
-            b = slot["b"]
-            return slot["h_labels"][:b].numpy().copy(), slot["h_logits"][:b].numpy().copy()
-
-        pending = []
+        ctx = self.model._context(self.device.index or 0)
         for batch in batches:
-            b = int(batch.shape[0]) if getattr(batch, "ndim", 1) == 2 else 1
-            cap = max(b, max_batch or 0)
-            if len(slots) < 2:
-                slots.append(make_slot(cap))
-                slot = slots[-1]
+            if torch.is_tensor(batch) and batch.dtype == torch.int16 and batch.dim() == 2 and batch.shape[1] == n \
+                    and not batch.is_cuda and batch.is_contiguous():
+                src = batch
             else:
-                slot = pending.pop(0)  # oldest in flight: hand its results out before reusing its buffers
-                yield collect(slot)
-                if slot["cap"] < b:
-                    slot.update(make_slot(b))
-            launch(slot, batch)
-            pending.append(slot)
-        for slot in pending:
-            yield collect(slot)
+                src = np.ascontiguousarray(fix_length(np.atleast_2d(np.asarray(batch, dtype=np.int16)), n))
+            logits, labels = ctx.infer_host_i16(src)
+            yield labels, logits
 
     def infer_files(self, paths: Sequence[str]) -> List[Tuple[int, str]]:
         clips = []

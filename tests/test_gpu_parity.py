@@ -668,23 +668,51 @@ def test_trainer_checkpoint_loads(dev, tmp_path, e2e_golden):
     assert np.abs(m.forward(x).cpu().numpy() - (g["he.logits"][:16] + 1.0)).max() <= TOL
 
 
-def test_host_ingest_double_buffered(dev, e2e_golden):
-    """KeywordSpotter.infer_batches (pinned staging, H2D on a copy stream overlapped with compute) returns, batch
-    by batch and in order, exactly what the device-resident fused call returns -- ragged batch sizes, numpy and
-    pre-pinned inputs."""
+def test_host_ingest_pipeline(native, dev, e2e_golden):
+    """kws_infer_host_i16 (pack threads -> pinned staging -> H2D || MFCC + DS-CNN || D2H, chunk by chunk) returns exactly
+    what the device-resident fused call returns: ragged batch sizes around the chunk size, every pipeline shape, numpy
+    (pageable), CPU-tensor and pinned inputs; KeywordSpotter.infer_batches yields batch by batch, in order."""
+    from kws.common.errors import ModelError
     from kws.inference import KeywordSpotter
-    from kws.libs.models import DepthwiseSeparableConv
 
     model = he_model(e2e_golden)
+    big = synth_clips(2500, 31, "uniform")
+    big[100:148] = e2e_golden["clips"]
+    want_logits, want_labels = model.infer_pcm16(torch.from_numpy(big).to(dev))
+    want_logits, want_labels = want_logits.cpu().numpy(), want_labels.cpu().numpy()
+    c = native.Context(0)
+    try:
+        c.load_dscnn(e2e_golden["he.blob"], 12)
+        for chunk, slots, threads in ((0, 0, 0), (100, 2, 1), (512, 4, -1), (3000, 3, 3), (1, 16, 2)):
+            c.ingest_config(chunk, slots, threads)
+            n = 2500 if chunk != 1 else 40
+            logits, labels = c.infer_host_i16(big[:n])
+            assert np.array_equal(logits, want_logits[:n]) and np.array_equal(labels, want_labels[:n]), (chunk, slots, threads)
+        c.ingest_config(0, 0, 0)
+        for n in (1, 1023, 1024, 1025, 2049):
+            logits, labels = c.infer_host_i16(big[:n])
+            assert np.array_equal(logits, want_logits[:n]) and np.array_equal(labels, want_labels[:n]), n
+        pinned = torch.from_numpy(big).pin_memory()
+        logits, labels = c.infer_host_i16(pinned)                   # the DMA reads the caller's pinned buffer
+        assert np.array_equal(logits, want_logits) and np.array_equal(labels, want_labels)
+        logits, labels = c.infer_host_i16(torch.from_numpy(big))    # pageable CPU tensor
+        assert np.array_equal(logits, want_logits)
+        with pytest.raises(ModelError):
+            c.ingest_config(0, 1, 0)                                # fewer than two slots cannot overlap anything
+    finally:
+        c.close()
     sp = KeywordSpotter(model)
-    batches = [synth_clips(b, seed, "uniform") for seed, b in enumerate([64, 7, 130, 1, 64])]
+    batches = [synth_clips(b, seed, "uniform") for seed, b in enumerate([64, 7, 1300, 1, 64])]
     mixed = [b if i % 2 == 0 else torch.from_numpy(b).pin_memory() for i, b in enumerate(batches)]
     got = list(sp.infer_batches(mixed))
     assert len(got) == len(batches)
     for clips, (labels, logits) in zip(batches, got):
-        want_logits, want_labels = model.infer_pcm16(torch.from_numpy(clips).to(dev))
-        assert np.array_equal(labels, want_labels.cpu().numpy())
-        assert np.array_equal(logits, want_logits.cpu().numpy())
+        wl, wy = model.infer_pcm16(torch.from_numpy(clips).to(dev))
+        assert np.array_equal(labels, wy.cpu().numpy()) and np.array_equal(logits, wl.cpu().numpy())
+    labels, logits = sp.infer_pcm16(big[:10, :15000])               # short clips are zero-padded to one second
+    padded = np.concatenate([big[:10, :15000], np.zeros((10, 1000), np.int16)], axis=1)
+    wl, _ = model.infer_pcm16(torch.from_numpy(padded).to(dev))
+    assert np.array_equal(logits, wl.cpu().numpy())
 
 
 def test_mfcc_batch_beyond_grid_limit(ctx, dev):
