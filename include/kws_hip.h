@@ -103,6 +103,17 @@ int kws_load_dscnn(kws_ctx* ctx, const float* blob, size_t n_floats, int num_cla
  * kws/libs/training.py:371) or NULL.  Replaces DepthwiseSeparableConv.forward (models.py:160-183). */
 int kws_forward_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
 
+/* One depthwise-separable block on an arbitrary map -- replaces DepthwiseSeparableConvBlock.forward
+ * (kws/libs/models.py:108-119) used on its own: depthwise Conv2d(C_in, C_in, kernel_size, stride, padding, groups=C_in)
+ * + bias, then pointwise Conv2d(C_in, C_out, 1, padding=padding) + bias, then ReLU.  d_x float32 [B,C_in,H,W]; d_dw_w
+ * [C_in,1,k,k], d_dw_b [C_in], d_pw_w [C_out,C_in,1,1], d_pw_b [C_out] (device pointers, the module's parameters as torch
+ * stores them); d_out float32 [B, C_out, Ho + 2*padding, Wo + 2*padding] with Ho = (H + 2*padding - k)/stride + 1: the
+ * pointwise padding adds a ring equal to relu(bias), as in the reference.  The four blocks of the DS-CNN do NOT go
+ * through this entry point: they run fused inside kws_forward_f32. */
+int kws_dsblock_forward_f32(kws_ctx* ctx, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w,
+                            const float* d_dw_b, const float* d_pw_w, const float* d_pw_b, int C_out, int kernel_size,
+                            int stride, int padding, float* d_out);
+
 /* Fused wav -> label: kws_mfcc_i16 into an internal workspace, then kws_forward_f32.  This is the
  * shape of inference(wav) -> label (kws/inference/inference_local.py:67-81), batched. */
 int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label);
@@ -117,7 +128,7 @@ int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, in
  * directly, without the pack stage. */
 int kws_infer_host_i16(kws_ctx* ctx, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label);
 /* Pipeline shape of kws_infer_host_i16: clips per chunk (default 1024), staging slots in flight (default 3, 2..16), host
- * threads of the pack stage (default min(8, cores/2); negative = pack on the calling thread).  0 keeps a default. */
+ * threads of the pack stage (default min(16, cores/2); negative = pack on the calling thread).  0 keeps a default. */
 int kws_ingest_config(kws_ctx* ctx, int chunk_clips, int n_slots, int pack_threads);
 
 /* Pre-size the internal workspaces for batches up to max_batch (otherwise grown on demand, which

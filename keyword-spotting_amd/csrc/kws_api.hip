@@ -720,22 +720,47 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     return KWS_OK;
 }
 
+// Grow the context's float scratch (convolution outputs between two kernels of one call) to at least `need` floats.
+static int grow_conv_ws(kws_ctx* c, size_t need, const char* fn) {
+    if (need <= c->conv_ws_floats) return KWS_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), need * sizeof(float)) != hipSuccess)
+        return fail(c, KWS_ENOMEM, std::string(fn) + ": workspace allocation failed");
+    if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
+    c->d_conv_ws = d;
+    c->conv_ws_floats = need;
+    return KWS_OK;
+}
+
+int kws_dsblock_forward_f32(kws_ctx* c, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w, const float* d_dw_b,
+                            const float* d_pw_w, const float* d_pw_b, int C_out, int kernel_size, int stride, int padding,
+                            float* d_out) {
+    int rc = check_batch(c, d_x, B, "kws_dsblock_forward_f32");
+    if (rc) return rc;
+    if (!d_dw_w || !d_dw_b || !d_pw_w || !d_pw_b || !d_out) return fail(c, KWS_EINVAL, "kws_dsblock_forward_f32: NULL pointer");
+    if (C_in < 1 || C_out < 1 || H < 1 || W < 1 || kernel_size < 1 || stride < 1 || padding < 0)
+        return fail(c, KWS_EINVAL, "kws_dsblock_forward_f32: sizes must be positive (padding >= 0)");
+    if (H + 2 * padding < kernel_size || W + 2 * padding < kernel_size)
+        return fail(c, KWS_EINVAL, "kws_dsblock_forward_f32: the kernel is larger than the padded input");
+    if (B > 65535) return fail(c, KWS_EUNSUPPORTED, "kws_dsblock_forward_f32: B must be <= 65535 per call");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int Ho = (H + 2 * padding - kernel_size) / stride + 1, Wo = (W + 2 * padding - kernel_size) / stride + 1;
+    rc = grow_conv_ws(c, (size_t)B * C_in * Ho * Wo, "kws_dsblock_forward_f32");
+    if (rc) return rc;
+    HIP_TRY(c, launch_dsblock(c->stream, d_x, B, C_in, H, W, d_dw_w, d_dw_b, d_pw_w, d_pw_b, C_out, kernel_size, stride, padding,
+                              c->d_conv_ws, d_out));
+    return KWS_OK;
+}
+
 int kws_forward_cnn_trad_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label) {
     int rc = check_batch(c, d_feat, B, "kws_forward_cnn_trad_f32");
     if (rc) return rc;
     if (!d_logits) return fail(c, KWS_EINVAL, "kws_forward_cnn_trad_f32: d_logits is NULL");
     if (!c->cnntrad_ready) return fail(c, KWS_ESTATE, "kws_forward_cnn_trad_f32: no model loaded (kws_load_cnn_trad)");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t need = (size_t)B * 64 * 297;
-    if (need > c->conv_ws_floats) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        float* d = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&d), need * sizeof(float)) != hipSuccess)
-            return fail(c, KWS_ENOMEM, "kws_forward_cnn_trad_f32: workspace allocation failed");
-        if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
-        c->d_conv_ws = d;
-        c->conv_ws_floats = need;
-    }
+    rc = grow_conv_ws(c, (size_t)B * 64 * 297, "kws_forward_cnn_trad_f32");
+    if (rc) return rc;
     {
         ProfScope ps(c, KWS_K_CNNTRAD_CONV);
         HIP_TRY(c, launch_cnntrad_conv(c->stream, c->tw, d_feat, B, c->d_conv_ws));

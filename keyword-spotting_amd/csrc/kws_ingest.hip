@@ -103,7 +103,7 @@ struct IngestSlot {
 
 struct Ingest {
     int chunk = 0, n_slots = 0, n_samples = 0, classes = 0;
-    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipStream_t copy_in[2] = {nullptr, nullptr}, copy_out = nullptr;  // two H2D streams: consecutive chunks ride different DMA engines
     std::vector<IngestSlot> slots;
     PackPool* pool = nullptr;
     int pool_threads = 0;
@@ -125,9 +125,12 @@ static void ingest_release(Ingest* g) {
         if (s.drained) (void)hipEventDestroy(s.drained);
     }
     g->slots.clear();
-    if (g->copy_in) (void)hipStreamDestroy(g->copy_in);
+    for (auto& st : g->copy_in) {
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+    }
     if (g->copy_out) (void)hipStreamDestroy(g->copy_out);
-    g->copy_in = g->copy_out = nullptr;
+    g->copy_out = nullptr;
     g->chunk = g->n_slots = 0;
 }
 
@@ -146,7 +149,7 @@ static int ingest_prepare(kws_ctx* c) {
     if (!g) return fail(c, KWS_ENOMEM, "kws_infer_host_i16: out of host memory");
     const int chunk = g->want_chunk > 0 ? g->want_chunk : 1024;
     const int n_slots = g->want_slots > 0 ? g->want_slots : 3;
-    int threads = g->want_threads > 0 ? g->want_threads : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    int threads = g->want_threads > 0 ? g->want_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
     if (g->want_threads < 0) threads = 0;  // pack on the calling thread
     const int n_samples = c->fp.n_samples, classes = c->mw.num_classes;
     if (!g->pool || g->pool_threads != threads) {
@@ -158,7 +161,8 @@ static int ingest_prepare(kws_ctx* c) {
     if (g->chunk == chunk && g->n_slots == n_slots && g->n_samples == n_samples && g->classes == classes) return KWS_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     ingest_release(g);
-    HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_in, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_in[0], hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_in[1], hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_out, hipStreamNonBlocking));
     g->slots.resize(n_slots);
     const size_t in_b = sizeof(int16_t) * (size_t)chunk * n_samples, lg_b = sizeof(float) * (size_t)chunk * classes,
@@ -242,8 +246,8 @@ int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits,
             break;
         }
     const bool direct = is_pinned_host(h_wav);  // the DMA can read the caller's buffer: no pack stage
-    int next = 0;
-    for (int first = 0; first < B; first += g->chunk, next = (next + 1) % g->n_slots) {
+    int next = 0, lane = 0;
+    for (int first = 0; first < B; first += g->chunk, next = (next + 1) % g->n_slots, lane ^= 1) {
         IngestSlot& s = g->slots[next];
         rc = ingest_collect(c, s, h_logits, h_label);  // blocks only if this slot's previous chunk is still in flight
         if (rc) return rc;
@@ -254,8 +258,8 @@ int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits,
             g->pool->copy(s.h_in, src, bytes);
             src = s.h_in;
         }
-        HIP_TRY(c, hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, g->copy_in));
-        HIP_TRY(c, hipEventRecord(s.staged, g->copy_in));
+        HIP_TRY(c, hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, g->copy_in[lane]));
+        HIP_TRY(c, hipEventRecord(s.staged, g->copy_in[lane]));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.staged, 0));
         rc = kws_infer_i16(c, s.d_in, count, s.d_logits, s.d_label);
         if (rc) return rc;

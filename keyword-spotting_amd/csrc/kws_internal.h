@@ -133,6 +133,11 @@ hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const flo
 hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const float* d_conv_ws, int B, float* d_logits,
                                 int32_t* d_label);
 
+// Standalone depthwise-separable block on an arbitrary [B, C_in, H, W] map (kws_dsblock.hip); d_ws: B*C_in*Ho*Wo floats.
+hipError_t launch_dsblock(hipStream_t s, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w, const float* d_dw_b,
+                          const float* d_pw_w, const float* d_pw_b, int C_out, int k, int stride, int pad, float* d_ws,
+                          float* d_out);
+
 hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "kws_load_dscnn": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
     "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
+    "kws_dsblock_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, _f32p]),
     "kws_infer_host_i16": (C.c_int, [_c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kws_ingest_config": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_int]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
@@ -226,6 +228,11 @@ class Context:
             self._lib.kws_infer_i16(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
             ModelError,
         )
+
+    def dsblock_forward_f32(self, x, dw_w, dw_b, pw_w, pw_b, kernel_size, stride, padding, out):
+        B, c_in, H, W = (int(v) for v in x.shape)
+        self._check(self._lib.kws_dsblock_forward_f32(self._h, _ptr(x), B, c_in, H, W, _ptr(dw_w), _ptr(dw_b), _ptr(pw_w), _ptr(pw_b),
+                                                      int(pw_w.shape[0]), int(kernel_size), int(stride), int(padding), _ptr(out)), ModelError)
 
     def infer_host_i16(self, wav: np.ndarray, logits: np.ndarray = None, label: np.ndarray = None):
         """Host ``int16[B,n]`` (numpy array or CPU torch tensor, pageable or pinned) -> host (logits float32[B,C], labels

@@ -53,18 +53,53 @@ class KeywordSpottingModel(nn.Module, abc.ABC):
 
 
 class DepthwiseSeparableConvBlock(nn.Module):
-    """Parameter holder for one block: 3x3 depthwise + 1x1 pointwise (the pointwise keeps the
-    reference's ``padding=padding`` -- the relu(bias) ring -- which the fused kernel reproduces)."""
+    """One block: kxk depthwise + 1x1 pointwise + ReLU (the pointwise keeps the reference's ``padding=padding`` --
+    the relu(bias) ring, ``models.py:104-106``).  Inside ``DepthwiseSeparableConv`` the four blocks run fused in the
+    DS-CNN kernel and this module only holds their parameters; called on its own, ``forward`` is the general-shape
+    operator ``kws_dsblock_forward_f32`` (any ``[B, C_in, H, W]``, kernel size, stride and padding)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, padding: int = 1):
         super().__init__()
         self.depthwise = nn.Conv2d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
                                    groups=in_channels)
         self.pointwise = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=padding)
+        self.kernel_size, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
+        self._ctx = None
+        self._dev_params = None  # (fingerprint, tensors on the device)
+
+    def sync_weights(self) -> None:
+        """Force a re-upload at the next forward (needed only after edits through ``p.data``)."""
+        self._dev_params = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise ModelError("a DepthwiseSeparableConvBlock has no standalone kernel: blocks run fused inside "
-                         "DepthwiseSeparableConv.forward (kws_forward_f32)")
+        """``float32[B, C_in, H, W]`` on the GPU -> ``float32[B, C_out, Ho + 2p, Wo + 2p]`` (``models.py:108-119``)."""
+        from kws import _native
+
+        if not x.is_cuda:
+            raise ModelError("DepthwiseSeparableConvBlock.forward needs a CUDA/ROCm tensor: the forward is a HIP kernel "
+                             "and has no CPU fallback")
+        c_in = self.depthwise.in_channels
+        if x.dim() != 4 or x.shape[1] != c_in:
+            raise ModelError(f"expected input [B,{c_in},H,W], got {tuple(x.shape)}")
+        dev = x.device.index or 0
+        if self._ctx is None or self._ctx.device != dev:
+            self._ctx = _native.Context(dev, ModelError)
+            self._dev_params = None
+        params = (self.depthwise.weight, self.depthwise.bias, self.pointwise.weight, self.pointwise.bias)
+        fp = tuple((p.data_ptr(), p._version) for p in params)
+        if self._dev_params is None or self._dev_params[0] != fp:
+            self._dev_params = (fp, tuple(p.detach().to(x.device, torch.float32).contiguous() for p in params))
+        dw_w, dw_b, pw_w, pw_b = self._dev_params[1]
+        k, s, p = self.kernel_size, self.stride, self.padding
+        B, _, H, W = x.shape
+        if H + 2 * p < k or W + 2 * p < k:
+            raise ModelError(f"kernel size {k} exceeds the padded input {H + 2 * p} x {W + 2 * p}")
+        ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        self._ctx.use_torch_stream()
+        x = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, self.pointwise.out_channels, ho + 2 * p, wo + 2 * p), dtype=torch.float32, device=x.device)
+        self._ctx.dsblock_forward_f32(x, dw_w, dw_b, pw_w, pw_b, k, s, p, out)
+        return out
 
 
 class DepthwiseSeparableConv(KeywordSpottingModel):

@@ -76,6 +76,15 @@ def forward(state: dict, x: torch.Tensor, return_layers: bool = False):
     return logits
 
 
+def block_forward(params: dict, x: torch.Tensor, kernel_size: int = 3, stride: int = 1, padding: int = 1) -> torch.Tensor:
+    """``DepthwiseSeparableConvBlock.forward`` on its own (kws/libs/models.py:108-119): depthwise (groups = channels,
+    ``kernel_size``/``stride``/``padding``) -> pointwise 1x1 with the SAME ``padding`` -> ReLU.  ``params`` uses the
+    block's state_dict names (depthwise.weight, depthwise.bias, pointwise.weight, pointwise.bias)."""
+    c_in = x.shape[1]
+    h = F.conv2d(x, params["depthwise.weight"], params["depthwise.bias"], stride=stride, padding=padding, groups=c_in)
+    return F.relu(F.conv2d(h, params["pointwise.weight"], params["pointwise.bias"], stride=1, padding=padding))
+
+
 def predict(logits: torch.Tensor) -> torch.Tensor:
     """``torch.max(outputs, 1)`` indices (kws/libs/training.py:371)."""
     return torch.max(logits, 1)[1]

@@ -57,6 +57,12 @@ def e2e_golden():
     return np.load(os.path.join(GOLDEN, "e2e_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def dsblock_golden():
+    """DepthwiseSeparableConvBlock on its own: inputs, parameters and the imported reference module's outputs."""
+    return np.load(os.path.join(GOLDEN, "dsblock_golden.npz"))
+
+
 def synth_clips(batch: int, seed: int = 0, kind: str = "uniform") -> np.ndarray:
     """Synthetic int16 [batch,16000] clips of SURVEY.md section 8(d)."""
     rng = np.random.default_rng(seed)

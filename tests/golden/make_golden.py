@@ -9,6 +9,7 @@ Writes (data only -- inputs and expected outputs, no reference source):
                                     framesig(rect) / powspec outputs
   tests/golden/dscnn_golden.npz     seeded state_dicts + inputs -> reference
                                     DepthwiseSeparableConv logits, per-layer probes
+  tests/golden/dsblock_golden.npz   DepthwiseSeparableConvBlock on its own: four shapes -> reference outputs
   tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
                                     reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
                                     AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
@@ -272,7 +273,36 @@ def e2e_golden():
     print("e2e_golden.npz written; labels:", labels.tolist())
 
 
+def dsblock_golden():
+    """DepthwiseSeparableConvBlock (kws/libs/models.py:75-119) on its own, imported and run: three shapes incl. a
+    non-default kernel size / stride / padding and channel counts that are not multiples of the kernel's tiles."""
+    cases = [  # (c_in, c_out, k, stride, padding, B, H, W)
+        (64, 64, 3, 1, 1, 3, 9, 5),
+        (8, 24, 3, 1, 1, 2, 6, 7),
+        (20, 70, 5, 2, 2, 2, 11, 9),
+        (3, 5, 3, 1, 0, 1, 4, 4),
+    ]
+    save = {"cases": np.array(cases)}
+    for i, (ci, co, k, st, pd, B, H, W) in enumerate(cases):
+        torch.manual_seed(100 + i)
+        blk = ref_models.DepthwiseSeparableConvBlock(ci, co, kernel_size=k, stride=st, padding=pd).eval()
+        with torch.no_grad():
+            for prm in blk.parameters():
+                prm.copy_(torch.randn_like(prm) * (0.5 if prm.dim() > 1 else 0.3))
+            x = torch.randn(B, ci, H, W) * 2.0
+            y = blk(x)
+        o_y = o_dscnn.block_forward({n: t.detach() for n, t in blk.state_dict().items()}, x, k, st, pd)
+        np.testing.assert_allclose(o_y.numpy(), y.numpy(), rtol=0, atol=2e-6 * float(y.abs().max()))
+        save[f"c{i}.x"] = x.numpy()
+        save[f"c{i}.y"] = y.numpy()
+        for n, t in blk.state_dict().items():
+            save[f"c{i}.{n}"] = t.detach().numpy()
+        print(f"dsblock case {i}: in {tuple(x.shape)} -> out {tuple(y.shape)}")
+    np.savez_compressed(os.path.join(HERE, "dsblock_golden.npz"), **save)
+
+
 if __name__ == "__main__":
     sigproc_golden()
     dscnn_golden()
     e2e_golden()
+    dsblock_golden()

@@ -313,6 +313,31 @@ def test_argmax_ties_first_maximum_wins(native, ctx, dev, e2e_golden, use_mfma):
             assert (lb == lo).sum() >= 3 and not (lb == hi).any()
 
 
+def test_standalone_block_forward(dev, dsblock_golden):
+    """DepthwiseSeparableConvBlock.forward on its own (kws_dsblock_forward_f32) against the imported reference module's
+    outputs: four shapes incl. 5x5 / stride 2 / padding 2, padding 0, and channel counts off the kernel's tile sizes;
+    relative gate 2e-5 of the output's scale; the relu(bias) ring bit-exact."""
+    from kws.common.errors import ModelError
+    from kws.libs.models import DepthwiseSeparableConvBlock
+
+    g = dsblock_golden
+    for i, (ci, co, k, st, pd, B, H, W) in enumerate(g["cases"].tolist()):
+        blk = DepthwiseSeparableConvBlock(ci, co, kernel_size=k, stride=st, padding=pd)
+        blk.load_state_dict({n: torch.from_numpy(g[f"c{i}.{n}"]) for n in ("depthwise.weight", "depthwise.bias", "pointwise.weight",
+                                                                           "pointwise.bias")})
+        y = blk(torch.from_numpy(g[f"c{i}.x"]).to(dev)).cpu().numpy()
+        want = g[f"c{i}.y"]
+        assert y.shape == want.shape
+        err = float(np.abs(y - want).max())
+        assert err <= LAYER_RTOL * float(np.abs(want).max()), (i, err)
+        if pd:
+            assert np.array_equal(y[:, :, 0, :], want[:, :, 0, :]) and np.array_equal(y[:, :, :, -1], want[:, :, :, -1])
+    with pytest.raises(ModelError):
+        blk(torch.zeros(1, 3, 4, 4))                       # CPU tensor: no fallback
+    with pytest.raises(ModelError):
+        blk(torch.zeros(1, 4, 4, 4, device=dev))           # wrong channel count
+
+
 def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
     g = dscnn_golden
     ctx.load_dscnn(g["n01.blob"], 12)

@@ -220,6 +220,20 @@ def test_argmax_ties_follow_torch_max(e2e_golden):
     assert (g["tie_pair.label"] == lo).sum() >= 3 and not (g["tie_pair.label"] == hi).any()
 
 
+def test_standalone_block_matches_reference(dsblock_golden):
+    g = dsblock_golden
+    for i, (ci, co, k, st, pd, B, H, W) in enumerate(g["cases"].tolist()):
+        params = {n: torch.from_numpy(g[f"c{i}.{n}"]) for n in ("depthwise.weight", "depthwise.bias", "pointwise.weight", "pointwise.bias")}
+        y = o_dscnn.block_forward(params, torch.from_numpy(g[f"c{i}.x"]), k, st, pd).numpy()
+        want = g[f"c{i}.y"]
+        ho, wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+        assert y.shape == want.shape == (B, co, ho + 2 * pd, wo + 2 * pd)
+        assert np.abs(y - want).max() <= 2e-6 * np.abs(want).max()
+        if pd:  # the ring of the padded 1x1 convolution is relu(bias)
+            ring = np.maximum(g[f"c{i}.pointwise.bias"], 0)
+            assert np.array_equal(want[0, :, 0, :], np.broadcast_to(ring[:, None], want[0, :, 0, :].shape))
+
+
 def test_dscnn_shapes_and_relu_bias_ring():
     st = o_dscnn.random_state(seed=3)
     x = torch.randn(2, 1, 99, 10)

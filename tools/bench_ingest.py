@@ -55,7 +55,7 @@ def run(ctx, src, calls):
     return B * calls / dt, labels.copy()
 
 res = {}
-for name, (chunk, slots, threads) in {"default (1024 x 3 slots, 8 threads)": (0, 0, 0), "1 pack thread": (0, 0, 1), "4 pack threads": (0, 0, 4),
+for name, (chunk, slots, threads) in {"default (1024 x 3 slots, 16 threads)": (0, 0, 0), "8 pack threads": (0, 0, 8), "1 pack thread": (0, 0, 1), "4 pack threads": (0, 0, 4),
                                        "16 pack threads": (0, 0, 16), "chunk 512": (512, 0, 0), "chunk 2048": (2048, 0, 0),
                                        "chunk 4096 x 2 slots": (4096, 2, 0), "6 slots": (0, 6, 0)}.items():
     ctx = _native.Context(0)
