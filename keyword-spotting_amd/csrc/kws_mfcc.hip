@@ -122,6 +122,43 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
     dft8(v);  // over n1 -> k1 (register index)
 #pragma unroll
     for (int i = 1; i < 8; ++i) v[i] = cmul(v[i], t1[i]);  // W512^(lane*k1)
+#ifdef KWS_MFCC_XCHG_PERMLANE
+    // First exchange in registers -- an EXPERIMENT, not built by default (profiles/r02_mfcc_exchange_experiment.txt: LDS
+    // instructions -15 %, LDS-array cycles -10 %, LDS issue stalls -39 %, VALU instructions +10 %, kernel time +1 %: the
+    // kernel is bound by the SUM of its VALU and LDS time per wavefront, not by LDS alone).  Register index k1 (3 bits) <-> lane bits [5:3], the low
+    // lane bits stay.  Three swap stages: lane bit 5 <-> register bit 2 with v_permlane32_swap (upper half of v[i] <->
+    // lower half of v[i+4]), lane bit 4 <-> register bit 1 with v_permlane16_swap (odd 16-lane rows of v[i] <-> even rows
+    // of v[i+2]), lane bit 3 <-> register bit 0 through row_ror:8 (= lane ^ 8 inside a 16-lane row) fused into the selects.
+    {
+        uint32_t r[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            r[i][0] = __builtin_bit_cast(uint32_t, (float)v[i].x);
+            r[i][1] = __builtin_bit_cast(uint32_t, (float)v[i].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i][h]), "+v"(r[i + 4][h]));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (!(i & 2))
+#pragma unroll
+                for (int h = 0; h < 2; ++h) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(r[i][h]), "+v"(r[i + 2][h]));
+        const bool up = (lane & 8) != 0;  // this lane keeps r[odd] and receives into r[even]
+#pragma unroll
+        for (int i = 0; i < 8; i += 2)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t send = up ? r[i][h] : r[i + 1][h];
+                const uint32_t got = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128 /*row_ror:8*/, 0xf, 0xf, false);
+                r[i][h] = up ? got : r[i][h];
+                r[i + 1][h] = up ? r[i + 1][h] : got;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = cf{__builtin_bit_cast(float, r[i][0]), __builtin_bit_cast(float, r[i][1])};
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 8; ++i) xbuf[i * XROW + lane] = v[i];
     wave_lds_order();
@@ -146,6 +183,7 @@ __device__ __forceinline__ void fft512(cf (&v)[8], cf* xbuf, const cf (&t1)[8], 
         v[4] = {r4.x, r4.y}; v[5] = {r5.x, r5.y}; v[6] = {r6.x, r6.y}; v[7] = {r7.x, r7.y};
     }
     wave_lds_order();
+#endif
     dft8(v);  // over a -> c
 #pragma unroll
     // W64^(b*c).  The table is symmetric (W64^(q*i)): read as tw2[i][q], the eight distinct addresses of one
@@ -625,14 +663,17 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
     }
 }
 
+#ifndef KWS_MFCC_EU
+#define KWS_MFCC_EU 4
+#endif
 // amdgpu_waves_per_eu(4, 4): 128 registers, so that the four 4-wave workgroups the LDS admits per CU (16
 // wavefronts, 4 per SIMD) all become resident; the kernel is latency-bound on LDS round trips.
-__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
                                                                     float* __restrict__ out) {
     mfcc_body<int16_t>(p, t, wav, out);
 }
-__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
                                                                     const float* __restrict__ wav,
                                                                     float* __restrict__ out) {
     mfcc_body<float>(p, t, wav, out);
@@ -830,6 +871,10 @@ static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p
                                 int B, float* d_out) {
     dim3 grid((p.num_frames + MFCC_FRAMES_PER_WG - 1) / MFCC_FRAMES_PER_WG, B);
     const size_t lds = mfcc_lds_bytes(p);
+    if (lds > 64 * 1024) {  // geometries (or experiment shapes) beyond the default dynamic-LDS limit opt in per kernel
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     // grid.y is limited to 65535: split very large batches
     for (int b0 = 0; b0 < B; b0 += 65535) {
         const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
