@@ -13,7 +13,8 @@ synthetic clips per GPU: 4096 per GPU by default (weak scaling), or a contiguous
 scaling).  The model is the reference's DS-CNN, the only model the reference defines; its
 weights are the signal-preserving golden set (tests/golden/e2e_golden.npz, data generated from the imported reference).
 Clips are independent, so N GPUs = N shards with no collective on the data path; torch.distributed is used only for the
-barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
+barrier and the max-over-ranks of the timed region (two scalars: gloo by default, --dist-backend nccl for RCCL).  Rank 0
+prints ONE JSON line.
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script is its own launcher: a parent process that never
 touches the GPU starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays
@@ -587,38 +588,54 @@ def worker(args) -> int:
     if not cpu_selftest and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is a HIP library with no CPU fallback")
     dist = None
+    use_nccl = (not cpu_selftest) and args.dist_backend == "nccl"
     if cpu_selftest:
         dev = torch.device("cpu")
+        dev_index = -1
     else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # one GPU per rank; on a box with fewer GPUs than ranks (a rehearsal of the N > 1 path) ranks share devices
+        n_dev = torch.cuda.device_count()
+        dev_index = local_rank % max(n_dev, 1)
+        if use_nccl and n_dev < world:
+            raise SystemExit(f"--dist-backend nccl needs one GPU per rank ({n_dev} visible, {world} ranks)")
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if cpu_selftest:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        saved_stdout = os.dup(1)  # gloo's C++ side announces its connections on stdout: keep stdout for the one JSON line
+        os.dup2(2, 1)
+        try:
+            if use_nccl:
+                dist.init_process_group(backend="nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend="gloo")
+            dist.barrier(device_ids=[dev_index]) if use_nccl else dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+    ctl = dev if use_nccl else torch.device("cpu")  # where the control-plane scalars live
 
     def barrier():
         if world > 1:
-            if cpu_selftest:
-                dist.barrier()
+            if use_nccl:
+                dist.barrier(device_ids=[dev_index])
             else:
-                dist.barrier(device_ids=[local_rank])
+                dist.barrier()
 
     def reduce_max(x: float) -> float:
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def gather_floats(x: float):
         if world == 1:
             return [x]
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=ctl)
         outs = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         return [float(o.item()) for o in outs]
@@ -651,7 +668,7 @@ def worker(args) -> int:
     else:
         from kws import _native
 
-        ctx = _native.Context(local_rank)
+        ctx = _native.Context(dev_index)
         feat_out = None
         ct_state = None
         wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
@@ -680,6 +697,7 @@ def worker(args) -> int:
     local_elapsed = time.perf_counter() - t_local0
     per_rank = gather_floats(B * args.steps / local_elapsed)
     shard_sizes = [int(v) for v in gather_floats(float(B))]
+    devices = [int(v) for v in gather_floats(float(dev_index))]
 
     if cpu_selftest:
         if rank == 0:
@@ -708,7 +726,10 @@ def worker(args) -> int:
         }
         cfg = {"clips_per_gpu_per_step": shard_sizes if scaling == "strong" else B, "global_batch": total, "sharding": shard_note,
                "spinup_steps": args.spinup, "launcher": os.environ.get("KWS_BENCH_LAUNCHER", "torch.distributed.run" if world > 1 else "single process")}
-        multi = {"per_rank_clips_per_s": per_rank, "max_over_ranks_s": elapsed}
+        multi = {"per_rank_clips_per_s": per_rank, "max_over_ranks_s": elapsed, "devices": devices,
+                 "control_plane": ("nccl (RCCL)" if use_nccl else "gloo") + ": barrier + max-over-ranks of the timed region only"}
+        if len(set(devices)) < world:
+            multi["invalid_for_measurement"] = "ranks share a GPU: a rehearsal of the N > 1 path, not a scaling point"
         if args.model == "mfcc-only":
             out = {"metric": "1s 16kHz clips/sec, MFCC only (wav->features)", "value": value, "unit": "clips/s", **common,
                    "config": {"workload": f"configs[1]: batch={B}/GPU synthetic uniform int16 1s/16kHz clips, device-resident, "
@@ -824,6 +845,9 @@ def parse_args(argv=None):
                     help="all: at N = 1 the ds-cnn line also measures the other BASELINE configurations under `configs`")
     ap.add_argument("--config-steps", type=int, default=100, help="timed steps of each side configuration")
     ap.add_argument("--stream-hops", type=int, default=340, help="pushes per mode of the streaming configuration (first 40 untimed)")
+    ap.add_argument("--dist-backend", choices=["gloo", "nccl"], default="gloo",
+                    help="control plane of an N > 1 run (barrier and the max-over-ranks of the timed region; the data path has no "
+                         "collective): gloo over 127.0.0.1 by default -- nothing to gain from RCCL for two scalars -- or nccl (= RCCL)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the extra launch on the golden clips after the timed region (profile runs: exact launch counts)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)  # launcher rehearsal on CPU (gloo), tests only

@@ -44,8 +44,8 @@ def test_bench_launches_its_own_ranks(extra, scaling, shards):
            "--batch", "16", "--selftest-cpu"] + extra
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
-    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), proc.stdout[-1000:]   # stdout carries the JSON line and nothing else
     out = json.loads(lines[0])
     assert out["selftest"] and out["n_gpus"] == 2 and out["scaling"] == scaling and out["shards"] == shards
     assert len(out["per_rank_clips_per_s"]) == 2 and out["max_over_ranks_s"] > 0
