@@ -360,9 +360,13 @@ def dscnn_roofline(_native, launches, avg_ms, B, workload="ds-cnn"):
     }
 
 
-def leg_mfcc_only(args, _native, torch, dev, B, cpu_n):
-    """BASELINE.json configs[1]: the MFCC kernel alone on 4096 clips, vs the CPU loop."""
+def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
+    """BASELINE.json configs[1]: the MFCC kernel alone on 4096 clips, vs the CPU loop.  precise: the float64 front end
+    (KWS_FE_F64) instead of the fast float32 kernel -- what matching psf's float64 on every input costs."""
     ctx = _native.Context(dev.index)
+    kid = _native.KWS_K_MFCC_F64 if precise else _native.KWS_K_MFCC
+    if precise:
+        ctx.set_frontend_math(_native.FE_F64)
     clips = synth_clips(B, seed=100)
     wav = torch.from_numpy(clips).to(dev)
     feat = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
@@ -372,18 +376,19 @@ def leg_mfcc_only(args, _native, torch, dev, B, cpu_n):
     ctx.sync()
     ctx.prof_enable(True)
     ctx.prof_reset()
-    steps = args.config_steps
+    steps = max(10, args.config_steps // 5) if precise else args.config_steps
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     ctx.sync()
     dt = time.perf_counter() - t0
-    ms, n = ctx.prof_read(_native.KWS_K_MFCC)
+    ms, n = ctx.prof_read(kid)
     ctx.prof_enable(False)
     out = {"workload": f"configs[1]: batch={B} synthetic uniform int16 1s/16kHz clips, device-resident, MFCC(400/160/512, 26 mel, "
-                       "10 cep) -> float32 [B,1,99,10]", "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3,
-           "steps": steps, "dtype": "f32",
-           "roofline": hbm_roofline(_native, _native.KWS_K_MFCC, n, ms / max(n, 1), B, "mfcc-only")}
+                       "10 cep) -> float32 [B,1,99,10]" + (", float64 front end (KWS_FE_F64)" if precise else ""),
+           "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3,
+           "steps": steps, "dtype": "f64" if precise else "f32",
+           "roofline": hbm_roofline(_native, kid, n, ms / max(n, 1), B, "mfcc-only-f64" if precise else "mfcc-only")}
     if cpu_n > 0:
         from oracle import psf_mfcc as o_mfcc
 
@@ -669,6 +674,8 @@ def worker(args) -> int:
         from kws import _native
 
         ctx = _native.Context(dev_index)
+        if args.frontend_math == "f64":
+            ctx.set_frontend_math(_native.FE_F64)
         feat_out = None
         ct_state = None
         wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
@@ -710,7 +717,8 @@ def worker(args) -> int:
         return 0
 
     k_ms, k_n = ctx.prof_read(_native.KWS_K_DSCNN)
-    m_ms, m_n = ctx.prof_read(_native.KWS_K_MFCC)
+    mfcc_kid = _native.KWS_K_MFCC_F64 if args.frontend_math == "f64" else _native.KWS_K_MFCC
+    m_ms, m_n = ctx.prof_read(mfcc_kid)
     c_ms, c_n = ctx.prof_read(_native.KWS_K_CNNTRAD_CONV)
     d_ms, d_n = ctx.prof_read(_native.KWS_K_CNNTRAD_DENSE)
     ctx.prof_enable(False)
@@ -734,7 +742,7 @@ def worker(args) -> int:
             out = {"metric": "1s 16kHz clips/sec, MFCC only (wav->features)", "value": value, "unit": "clips/s", **common,
                    "config": {"workload": f"configs[1]: batch={B}/GPU synthetic uniform int16 1s/16kHz clips, device-resident, "
                                           "MFCC(400/160/512, 26 mel, 10 cep) -> float32 [B,1,99,10]", **cfg},
-                   "roofline": hbm_roofline(_native, _native.KWS_K_MFCC, m_n, mfcc_ms, B, "mfcc-only"), **multi}
+                   "roofline": hbm_roofline(_native, mfcc_kid, m_n, mfcc_ms, B, "mfcc-only"), **multi}
             if world == 1 and args.cpu_sample > 0:
                 from oracle import psf_mfcc as o_mfcc
 
@@ -774,11 +782,11 @@ def worker(args) -> int:
                                  f"DS-CNN end to end: batch={B}/GPU synthetic uniform int16 1s/16kHz clips (the batch shape of BASELINE "
                                  "configs[2], the reference's own model -- configs[2]'s literal cnn-trad-fpool3 is under configs.C3)")
                                 + ", device-resident, MFCC(400/160/512, 26 mel, 10 cep) + DS-CNN(12 classes, signal-preserving golden "
-                                  "weights) -> logits+label", **cfg},
+                                  "weights) -> logits+label" + (" [float64 front end]" if args.frontend_math == "f64" else ""), **cfg},
                 "roofline": dscnn_roofline(_native, k_n, dscnn_ms, B),
                 "hbm_read": {"bytes_per_clip": BYTES_PER_CLIP, "achieved_GBps_per_gpu": value / world * BYTES_PER_CLIP / 1e9,
                              "frac_of_8TBps": value / world * BYTES_PER_CLIP / PEAK_HBM_BPS},
-                "mfcc_kernel": {"kernel": _native.kernel_name(_native.KWS_K_MFCC), "avg_kernel_ms": mfcc_ms,
+                "mfcc_kernel": {"kernel": _native.kernel_name(mfcc_kid), "avg_kernel_ms": mfcc_ms,
                                 "clips_per_s": B / (mfcc_ms * 1e-3) if mfcc_ms > 0 else 0.0,
                                 "hbm_read_frac": (B / (mfcc_ms * 1e-3) * BYTES_PER_CLIP / PEAK_HBM_BPS) if mfcc_ms > 0 else 0.0,
                                 "f32_frac": (B / (mfcc_ms * 1e-3) * MFCC_FLOP_PER_CLIP / (PEAK_F32_TFLOPS * 1e12)) if mfcc_ms > 0 else 0.0},
@@ -808,6 +816,7 @@ def worker(args) -> int:
                 cpu_n = args.cpu_sample
                 legs = {}
                 for name, fn in (("C2_mfcc_only", lambda: leg_mfcc_only(args, _native, torch, dev, 4096, min(cpu_n, 256))),
+                                 ("C2_mfcc_only_float64", lambda: leg_mfcc_only(args, _native, torch, dev, 4096, min(cpu_n, 256), precise=True)),
                                  ("C3_cnn_trad_fpool3", lambda: leg_cnn_trad(args, _native, torch, dev, 4096, min(cpu_n, 64))),
                                  ("C4_dscnn_shard_1024", lambda: leg_dscnn_shard(args, _native, torch, dev, blob, 1024)),
                                  ("C5_stream_64", lambda: leg_stream(args, _native, torch, dev, blob, 64, args.stream_hops, cpu_n > 0))):
@@ -848,6 +857,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", choices=["gloo", "nccl"], default="gloo",
                     help="control plane of an N > 1 run (barrier and the max-over-ranks of the timed region; the data path has no "
                          "collective): gloo over 127.0.0.1 by default -- nothing to gain from RCCL for two scalars -- or nccl (= RCCL)")
+    ap.add_argument("--frontend-math", choices=["f32", "f64"], default="f32",
+                    help="f32: the fast front end (default, the headline); f64: KWS_FE_F64, float64 after framing as psf computes it")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the extra launch on the golden clips after the timed region (profile runs: exact launch counts)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)  # launcher rehearsal on CPU (gloo), tests only

@@ -71,10 +71,28 @@ const char* kws_last_error(kws_ctx* ctx);
  *   numcep 10, preemph 0.97, ceplifter 22                     (AudioConfig, audio_processor.py:37-46;
  *   psf.mfcc defaults for preemph / ceplifter / lowfreq 0 / highfreq sr/2 / appendEnergy True /
  *   rectangular window).  frame_len and frame_step are in samples (winlen*sr, winstep*sr rounded
- *   half up, as psf does).  Supported by the kernels: nfft == 512, frame_len <= 512, nfilt <= 64,
- *   numcep <= min(nfilt, 32); anything else returns KWS_EUNSUPPORTED. */
+ *   half up, as psf does).  Two kernels serve it:
+ *     the float32 kernel (the hot path) for nfft == 512, frame_len <= 512 and a filterbank that spans bins 0..256;
+ *     the float64 kernel for every other geometry: nfft a power of two in [64, 4096] or any value in [2, 2048] (the
+ *     reference derives nfft = max(fft_size, int(winlen*samplerate)), audio_processor.py:268 -- e.g. 640 for a 40 ms
+ *     window), any frame_len (frames longer than nfft are truncated, as numpy.fft.rfft does).
+ *   Limits of both: nfilt <= 64, numcep <= min(nfilt, 32); anything else returns KWS_EUNSUPPORTED. */
 int kws_set_frontend(kws_ctx* ctx, int sample_rate, int n_samples, int frame_len, int frame_step,
                      int nfft, int nfilt, int numcep, float preemph, int ceplifter);
+
+/* Arithmetic of the front end -- replaces nothing in the reference (psf computes in float64 after a float32
+ * pre-emphasis); PCM scaling and pre-emphasis are bit-exact float32 in both.
+ *   KWS_FE_F32 (default): transform, mel sums, log and DCT in float32 -- the fast kernel.  Its rounding noise sits ~138 dB
+ *     below a frame's strongest spectral component: cepstra within 1e-4 of the reference for frames whose mel bands span
+ *     less than ~50 dB (noise, speech-like spectra), up to ~6e-4 on a clean tone over a quiet floor; logits within 1e-4.
+ *   KWS_FE_F64: everything after framing in float64, as psf does -- cepstra within the float32 rounding of the output
+ *     (~4e-6) on every input, at several times the kernel time.  Geometries the float32 kernel is not built for run in
+ *     float64 whatever this setting is; kws_frontend_math returns the arithmetic actually in use.  The streaming frame
+ *     kernel (kws_stream_push_i16) is float32 only. */
+#define KWS_FE_F32 0
+#define KWS_FE_F64 1
+int kws_set_frontend_math(kws_ctx* ctx, int math);
+int kws_frontend_math(kws_ctx* ctx);
 
 /* Frames per clip (1 + ceil((n_samples - frame_len)/frame_step), sigproc.py:31-35) and numcep. */
 int kws_frontend_shape(kws_ctx* ctx, int* num_frames, int* numcep);
@@ -245,13 +263,17 @@ int kws_framesig_f32(kws_ctx* ctx, const float* d_signal, int n, int frame_len, 
 int kws_spec512_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int frame_len, int power,
                     float* d_spec);
 
+/* The same for any NFFT (sigproc.py:55-90 takes any): NFFT == 512 runs the kernel above, any other length -- a power of
+ * two in [64, 4096] or any value in [2, 2048] -- a float64 transform (FFT / direct DFT) with float32 output. */
+int kws_spec_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int frame_len, int nfft, int power, float* d_spec);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 
 /* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
  * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
  * launch count per kernel id since the last kws_prof_reset.  The two kernels of an eager kws_stream_push_i16 are timed
  * too (KWS_K_STREAM_FRAME, KWS_K_DSCNN); a push replayed as a hipGraph is not (events cannot bracket a node). */
-enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_STREAM_FRAME = 4, KWS_K_COUNT = 5 };
+enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_STREAM_FRAME = 4, KWS_K_MFCC_F64 = 5, KWS_K_COUNT = 6 };
 int kws_prof_enable(kws_ctx* ctx, int on);
 int kws_prof_reset(kws_ctx* ctx);
 int kws_prof_read(kws_ctx* ctx, int kernel_id, double* total_ms, int* launches);

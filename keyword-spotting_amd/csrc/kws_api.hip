@@ -11,7 +11,7 @@
 namespace kws {
 
 const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel",
-                                               "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel"};
+                                               "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel", "kws_mfcc_f64_kernel"};
 
 // ------------------------------------------------------------------------------------------------
 // Host tables (double precision, then rounded once to float32).
@@ -225,6 +225,7 @@ void kws_destroy(kws_ctx* c) {
             (void)hipEventDestroy(p.b);
         }
     if (c->d_fe) (void)hipFree(c->d_fe);
+    if (c->d_spec_tw64) (void)hipFree(c->d_spec_tw64);
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_cnntrad) (void)hipFree(c->d_cnntrad);
     if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
@@ -265,28 +266,61 @@ int kws_sync(kws_ctx* c) {
 int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, int frame_step, int nfft, int nfilt,
                      int numcep, float preemph, int ceplifter) {
     if (!c) return KWS_EINVAL;
-    if (sample_rate <= 0 || n_samples <= 0 || frame_len <= 0 || frame_step <= 0 || nfilt <= 0 || numcep <= 0)
+    if (sample_rate <= 0 || n_samples <= 0 || frame_len <= 0 || frame_step <= 0 || nfilt <= 0 || numcep <= 0 || nfft < 2)
         return fail(c, KWS_EINVAL, "kws_set_frontend: sizes must be positive");
-    if (nfft != NFFT) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: only nfft == 512 is implemented");
-    if (frame_len > NFFT) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: frame_len must be <= 512");
     if (nfilt > MAX_NFILT || numcep > MAX_NUMCEP || numcep > nfilt)
         return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: need nfilt <= 64 and numcep <= min(nfilt, 32)");
+    int log2n = 0;
+    if ((nfft & (nfft - 1)) == 0)
+        for (int v = nfft; v > 1; v >>= 1) ++log2n;
+    if (nfft > 4096 || (log2n == 0 && nfft > 2048) || (log2n > 0 && nfft < 64))
+        return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: nfft must be a power of two in [64, 4096] or any value in [2, 2048]");
+    std::vector<int> edges;
+    mel_edges(nfilt, nfft, sample_rate, edges);
+    for (size_t i = 0; i + 1 < edges.size(); ++i)
+        if (edges[i + 1] < edges[i] || edges[i] < 0 || edges[i + 1] > nfft / 2)
+            return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: mel edges are not monotone inside [0, nfft/2]");
+    // The float32 kernel is built for nfft = 512, frames of at most 512 samples and filterbanks its sparse lane layout can
+    // hold; every other geometry runs on the float64 kernel (kws_mfcc_f64.hip).
     MelHost mel;
     std::string err;
-    if (!build_mel_host(nfilt, nfft, sample_rate, mel, err)) return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: " + err);
-    if (mel.edges.front() != 0 || mel.edges.back() != nfft / 2)
-        return fail(c, KWS_EUNSUPPORTED, "kws_set_frontend: the mel filterbank must span bins 0 .. nfft/2");
+    bool fast = nfft == NFFT && frame_len <= NFFT && build_mel_host(nfilt, nfft, sample_rate, mel, err) &&
+                mel.edges.front() == 0 && mel.edges.back() == nfft / 2;
+    if (!fast) {
+        mel = MelHost();
+        mel.k0.assign(64, 0);
+        mel.rw.assign(MEL_CHUNK * 64, 0.f);
+        mel.fw.assign(MEL_CHUNK * 64, 0.f);
+        mel.gather.assign(64, 0u);
+        mel.slot.assign(NFFT / 2, 0);
+        mel.seg.assign(64, 0);
+    }
     std::vector<float> dct;
     build_dct_lifter_host(nfilt, numcep, ceplifter, dct);
     std::vector<float2> tw;
     build_twiddle_host(tw);
+    // float64 tables: twiddles (cos, -sin)(2 pi k / nfft), DCT-II(ortho) x lifter
+    const double pi = 3.14159265358979323846;
+    std::vector<double> tw64(2 * (size_t)nfft), dct64((size_t)numcep * nfilt);
+    for (int k = 0; k < nfft; ++k) {
+        const double a = 2.0 * pi * k / nfft;
+        tw64[2 * k] = std::cos(a);
+        tw64[2 * k + 1] = -std::sin(a);
+    }
+    for (int i = 0; i < numcep; ++i) {
+        const double lift = ceplifter > 0 ? 1.0 + (ceplifter / 2.0) * std::sin(pi * i / ceplifter) : 1.0;
+        for (int j = 0; j < nfilt; ++j)
+            dct64[(size_t)i * nfilt + j] = lift * (i == 0 ? std::sqrt(1.0 / nfilt) : std::sqrt(2.0 / nfilt) * std::cos(pi * i * (2 * j + 1) / (2.0 * nfilt)));
+    }
 
-    // one device allocation: twiddle | k0 | rw | fw | gather | dct   (each 256-byte aligned)
+    // one device allocation, every table 256-byte aligned
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
                  o_fw = al(o_rw + sizeof(float) * MEL_CHUNK * 64), o_g = al(o_fw + sizeof(float) * MEL_CHUNK * 64),
                  o_dct = al(o_g + sizeof(uint32_t) * 64), o_slot = al(o_dct + sizeof(float) * dct.size()),
-                 o_seg = al(o_slot + sizeof(int) * (NFFT / 2)), total = al(o_seg + sizeof(int) * 64);
+                 o_seg = al(o_slot + sizeof(int) * (NFFT / 2)), o_tw64 = al(o_seg + sizeof(int) * 64),
+                 o_edges = al(o_tw64 + sizeof(double) * tw64.size()), o_dct64 = al(o_edges + sizeof(int) * edges.size()),
+                 total = al(o_dct64 + sizeof(double) * dct64.size());
     std::vector<unsigned char> host(total, 0);
     memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
     memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
@@ -296,6 +330,9 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     memcpy(&host[o_dct], dct.data(), sizeof(float) * dct.size());
     memcpy(&host[o_slot], mel.slot.data(), sizeof(int) * (NFFT / 2));
     memcpy(&host[o_seg], mel.seg.data(), sizeof(int) * 64);
+    memcpy(&host[o_tw64], tw64.data(), sizeof(double) * tw64.size());
+    memcpy(&host[o_edges], edges.data(), sizeof(int) * edges.size());
+    memcpy(&host[o_dct64], dct64.data(), sizeof(double) * dct64.size());
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
@@ -318,6 +355,9 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->ft.dct = reinterpret_cast<const float*>(b + o_dct);
     c->ft.mel_slot = reinterpret_cast<const int*>(b + o_slot);
     c->ft.mel_seg = reinterpret_cast<const int*>(b + o_seg);
+    c->ft.tw64 = reinterpret_cast<const double*>(b + o_tw64);
+    c->ft.mel_edges = reinterpret_cast<const int*>(b + o_edges);
+    c->ft.dct64 = reinterpret_cast<const double*>(b + o_dct64);
 
     FrontendParams& p = c->fp;
     p.n_samples = n_samples;
@@ -332,10 +372,26 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     // 16-byte PCM loads: every clip base and every workgroup's first sample must be multiples of 8 samples
     // (the pointer itself is checked per call; the tail of a clip falls back to guarded scalar loads)
     p.vec_ok = (n_samples % 8 == 0) && ((MFCC_FRAMES_PER_WG * frame_step) % 8 == 0);
+    p.nfft = nfft;
+    p.log2_nfft = log2n;
     c->sample_rate = sample_rate;
+    c->nfft = nfft;
     c->ceplifter = ceplifter;
+    c->fe_fast_ok = fast;
     c->fe_ready = true;
     return KWS_OK;
+}
+
+int kws_set_frontend_math(kws_ctx* c, int math) {
+    if (!c) return KWS_EINVAL;
+    if (math != KWS_FE_F32 && math != KWS_FE_F64) return fail(c, KWS_EINVAL, "kws_set_frontend_math: math must be KWS_FE_F32 or KWS_FE_F64");
+    c->fe_math = math;
+    return KWS_OK;
+}
+
+int kws_frontend_math(kws_ctx* c) {
+    if (!c || !c->fe_ready) return KWS_EINVAL;
+    return (c->fe_math == KWS_FE_F64 || !c->fe_fast_ok) ? KWS_FE_F64 : KWS_FE_F32;
 }
 
 int kws_frontend_shape(kws_ctx* c, int* num_frames, int* numcep) {
@@ -484,6 +540,11 @@ int kws_mfcc_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_out) {
     HIP_TRY(c, hipSetDevice(c->device));
     FrontendParams p = c->fp;
     if ((reinterpret_cast<uintptr_t>(d_wav) & 15) != 0) p.vec_ok = 0;
+    if (c->fe_math == KWS_FE_F64 || !c->fe_fast_ok) {
+        ProfScope ps(c, KWS_K_MFCC_F64);
+        HIP_TRY(c, launch_mfcc_f64(c->stream, p, c->ft, d_wav, B, d_out));
+        return KWS_OK;
+    }
     ProfScope ps(c, KWS_K_MFCC);
     HIP_TRY(c, launch_mfcc(c->stream, p, c->ft, d_wav, B, d_out));
     return KWS_OK;
@@ -495,6 +556,11 @@ int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
     if (!d_out) return fail(c, KWS_EINVAL, "kws_mfcc_f32: d_out is NULL");
     if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_mfcc_f32: front end not configured");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->fe_math == KWS_FE_F64 || !c->fe_fast_ok) {
+        ProfScope ps(c, KWS_K_MFCC_F64);
+        HIP_TRY(c, launch_mfcc_f64_f32in(c->stream, c->fp, c->ft, d_wav, B, d_out));
+        return KWS_OK;
+    }
     ProfScope ps(c, KWS_K_MFCC);
     HIP_TRY(c, launch_mfcc_f32(c->stream, c->fp, c->ft, d_wav, B, d_out));
     return KWS_OK;
@@ -598,6 +664,8 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     if (!c) return KWS_EINVAL;
     if (n_streams <= 0) return fail(c, KWS_EINVAL, "kws_stream_open: n_streams must be positive");
     if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_stream_open: front end not configured");
+    if (!c->fe_fast_ok)
+        return fail(c, KWS_EUNSUPPORTED, "kws_stream_open: the streaming frame kernel is built for nfft == 512 and frames of at most 512 samples");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     stream_free(c);
@@ -977,6 +1045,41 @@ int kws_spec512_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame
     if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_spec512_f32: front end tables not built");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, launch_spec512(c->stream, c->ft, d_frames, num_frames, frame_len, power, d_spec));
+    return KWS_OK;
+}
+
+int kws_spec_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame_len, int nfft, int power, float* d_spec) {
+    int rc = check_batch(c, d_frames, num_frames, "kws_spec_f32");
+    if (rc) return rc;
+    if (!d_spec || frame_len <= 0 || nfft < 2) return fail(c, KWS_EINVAL, "kws_spec_f32: bad argument");
+    if (nfft == NFFT) return kws_spec512_f32(c, d_frames, num_frames, frame_len, power, d_spec);
+    int log2n = 0;
+    if ((nfft & (nfft - 1)) == 0)
+        for (int v = nfft; v > 1; v >>= 1) ++log2n;
+    if (nfft > 4096 || (log2n == 0 && nfft > 2048) || (log2n > 0 && nfft < 64))
+        return fail(c, KWS_EUNSUPPORTED, "kws_spec_f32: NFFT must be a power of two in [64, 4096] or any value in [2, 2048]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->spec_nfft != nfft) {  // float64 twiddles of this transform length, kept until another length is asked for
+        std::vector<double> tw(2 * (size_t)nfft);
+        const double pi = 3.14159265358979323846;
+        for (int k = 0; k < nfft; ++k) {
+            tw[2 * k] = std::cos(2.0 * pi * k / nfft);
+            tw[2 * k + 1] = -std::sin(2.0 * pi * k / nfft);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        double* d = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * tw.size()) != hipSuccess)
+            return fail(c, KWS_ENOMEM, "kws_spec_f32: device allocation failed");
+        hipError_t e = hipMemcpy(d, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return fail_hip(c, e, "kws_spec_f32: hipMemcpy");
+        }
+        if (c->d_spec_tw64) (void)hipFree(c->d_spec_tw64);
+        c->d_spec_tw64 = d;
+        c->spec_nfft = nfft;
+    }
+    HIP_TRY(c, launch_spec_f64(c->stream, c->d_spec_tw64, d_frames, num_frames, frame_len, nfft, log2n, power, d_spec));
     return KWS_OK;
 }
 

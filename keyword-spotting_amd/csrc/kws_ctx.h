@@ -21,8 +21,12 @@ struct kws_ctx {
     int sample_rate = 16000, nfft = NFFT, ceplifter = 22;
     FrontendParams fp{};
     bool fe_ready = false;
+    bool fe_fast_ok = false;      // the float32 kernel covers this geometry (nfft 512, frame_len <= 512, sparse mel layout fits)
+    int fe_math = KWS_FE_F32;     // requested arithmetic (kws_set_frontend_math); geometries without a fast kernel run in float64 anyway
     void* d_fe = nullptr;  // one allocation holding all front-end tables
     FrontendTables ft{};
+    double* d_spec_tw64 = nullptr;  // float64 twiddles of kws_spec_f32's last transform length
+    int spec_nfft = 0;
 
     // model
     float* d_model = nullptr;

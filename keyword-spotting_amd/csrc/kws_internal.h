@@ -39,6 +39,8 @@ struct FrontendParams {
     float preemph;
     int chunk_samples;     // samples staged per workgroup = (MFCC_FRAMES_PER_WG-1)*frame_step + frame_len
     int vec_ok;            // 1 -> every workgroup's first sample is 16-byte aligned (vector PCM loads legal)
+    int nfft;              // transform length (the float32 kernel is built for 512; the float64 kernel takes any)
+    int log2_nfft;         // log2(nfft) when nfft is a power of two, else 0 (float64 kernel: FFT vs direct DFT)
 };
 
 // Device tables of the front end (all float32 unless noted), built on the host in double.
@@ -51,6 +53,10 @@ struct FrontendTables {
     const int* mel_slot;       // [256]      power-buffer slot of bin k = 8*chunk(k) + (k - first bin of the chunk)
     const int* mel_seg;        // [64]       per chunk: bit d (0..2) = chunk + 2^d is in the same segment; bit 6 = no segment straddles a 16-lane row; bit 7 = deep
     const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
+    // float64 kernel (kws_mfcc_f64.hip)
+    const double* tw64;        // [nfft][2]  (cos, -sin)(2*pi*k/nfft)
+    const int* mel_edges;      // [nfilt+2]  psf's bin edges
+    const double* dct64;       // [numcep][nfilt]  DCT-II ortho x lifter
 };
 
 // Host-side construction of the sparse mel decomposition (also used by the host-only ABI helpers).
@@ -72,6 +78,12 @@ hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTab
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t,
                            const float* d_wav, int B, float* d_out);
 size_t mfcc_lds_bytes(const FrontendParams& p);
+// The float64 front end: any nfft (power of two up to 4096: FFT; otherwise up to 2048: direct DFT), any frame length.
+hipError_t launch_mfcc_f64(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B, float* d_out);
+hipError_t launch_mfcc_f64_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
+                                 float* d_out);
+hipError_t launch_spec_f64(hipStream_t s, const double* d_tw64, const float* d_frames, int num_frames, int frame_len, int nfft,
+                           int log2n, int power, float* d_spec);
 // Streaming: one hop of frame_step new samples per stream -> one new MFCC frame per stream in the feature ring.
 // d_hops: int[2] = {hops pushed so far, finished-workgroup counter}; the kernel advances the hop count itself.
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,

@@ -19,7 +19,8 @@ from kws.common.errors import AudioProcessingError, KWSError, ModelError
 LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME = 0, 1, 2, 3, 4
+KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME, KWS_K_MFCC_F64 = 0, 1, 2, 3, 4, 5
+FE_F32, FE_F64 = 0, 1  # KWS_FE_F32 (default: the fast float32 front end) / KWS_FE_F64 (float64 after framing, as psf)
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64 + 64 * 477  # KWS_ACT_FLOATS_PER_CLIP
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
 PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16 (default): exact three-way bf16 split, six bf16 MFMAs per f32 product
@@ -36,6 +37,9 @@ SIGNATURES = {
     "kws_sync": (C.c_int, [_c_ctx]),
     "kws_last_error": (C.c_char_p, [_c_ctx]),
     "kws_set_frontend": (C.c_int, [_c_ctx] + [C.c_int] * 7 + [C.c_float, C.c_int]),
+    "kws_set_frontend_math": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_frontend_math": (C.c_int, [_c_ctx]),
+    "kws_spec_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "kws_frontend_shape": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kws_mfcc_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p]),
     "kws_mfcc_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p]),
@@ -158,6 +162,13 @@ class Context:
                                        float(preemph), ceplifter),
             AudioProcessingError,
         )
+
+    def set_frontend_math(self, math: int):
+        self._check(self._lib.kws_set_frontend_math(self._h, int(math)), AudioProcessingError)
+
+    def frontend_math(self) -> int:
+        """FE_F32 or FE_F64: the arithmetic kws_mfcc_* actually uses for the configured geometry."""
+        return int(self._lib.kws_frontend_math(self._h))
 
     def frontend_shape(self):
         nf, nc = C.c_int(), C.c_int()
@@ -304,6 +315,12 @@ class Context:
         self._check(
             self._lib.kws_framesig_f32(self._h, _ptr(sig), int(sig.numel()), int(frame_len), int(frame_step),
                                        _ptr(window) if window is not None else None, _ptr(frames)),
+            AudioProcessingError,
+        )
+
+    def spec_f32(self, frames, nfft, power, spec):
+        self._check(
+            self._lib.kws_spec_f32(self._h, _ptr(frames), int(frames.shape[0]), int(frames.shape[1]), int(nfft), 1 if power else 0, _ptr(spec)),
             AudioProcessingError,
         )
 

@@ -94,10 +94,15 @@ def fix_length(x: np.ndarray, size: int) -> np.ndarray:
 class AudioProcessor:
     """WAV -> fixed length -> (augment) -> MFCC, with the MFCC on the GPU."""
 
-    def __init__(self, dataset_path: Optional[Path], config: Optional[AudioConfig] = None, device: int = 0):
+    def __init__(self, dataset_path: Optional[Path], config: Optional[AudioConfig] = None, device: int = 0,
+                 precise: bool = False):
+        """``precise=True`` selects the float64 front end (``KWS_FE_F64``: everything after framing in float64, as psf
+        computes it) instead of the fast float32 kernel; geometries the fast kernel is not built for (``nfft != 512``,
+        i.e. ``frame_length * sample_rate > 512``) use it anyway."""
         self.config = config if config is not None else AudioConfig()
         self.dataset_path = Path(dataset_path) if dataset_path is not None else None
         self.device = device
+        self.precise = bool(precise)
         self._ctx = None
         self._ctx_key = None
         try:
@@ -171,6 +176,7 @@ class AudioProcessor:
         key = (n_samples, samplerate, numcep, nfft, _half_up(winlen * samplerate), _half_up(winstep * samplerate), nfilt)
         if self._ctx is None:
             self._ctx = _native.Context(self.device, AudioProcessingError)
+            self._ctx.set_frontend_math(_native.FE_F64 if self.precise else _native.FE_F32)
         if key != self._ctx_key:
             self._ctx.set_frontend(sample_rate=samplerate, n_samples=n_samples, frame_len=key[4], frame_step=key[5],
                                    nfft=nfft, nfilt=nfilt, numcep=numcep, preemph=0.97, ceplifter=22)
@@ -182,8 +188,9 @@ class AudioProcessor:
         """MFCC of one clip: float signal in [-1, 1] (or int16 PCM) -> ``float64[frames, numcep]``.
 
         Falsy arguments fall back to the config exactly as in the reference (``:260-268``); ``nfft`` is
-        accepted and ignored there too.  Values are computed in float32 on the GPU and returned as
-        float64 to keep the reference's dtype."""
+        accepted and ignored there too.  Values are computed on the GPU (float32 kernel, or float64 with
+        ``precise=True`` / for ``nfft != 512``), cross the boundary as float32 and are returned as float64 to keep the
+        reference's dtype."""
         import torch
 
         c = self.config

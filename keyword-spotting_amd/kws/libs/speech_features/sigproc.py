@@ -2,12 +2,13 @@
 
 Drop-in for ``kws/libs/speech_features/sigproc.py`` (``framesig`` ``:14-52``, ``magspec`` ``:55-77``,
 ``powspec`` ``:80-90``, ``preemphasis`` ``:93-103``): same names, arguments and shapes, executed by the
-HIP kernels behind ``kws_framesig_f32`` / ``kws_spec512_f32`` / ``kws_preemphasis_f32``.
+HIP kernels behind ``kws_framesig_f32`` / ``kws_spec_f32`` / ``kws_preemphasis_f32``.
 
 Differences that follow from running on the GPU, stated rather than hidden:
   * tensors must live on a CUDA/ROCm device -- there is no CPU implementation in this package;
-  * arithmetic is float32 (other floating dtypes are cast in and the result cast back);
-  * ``NFFT`` must be 512 (the only transform size the wavefront FFT implements).
+  * values cross the boundary as float32 (other floating dtypes are cast in and the result cast back); the transform
+    itself is float32 for ``NFFT == 512`` (the hot path's wavefront FFT) and float64 for every other length;
+  * ``NFFT`` may be any power of two in [64, 4096] or any value in [2, 2048].
 """
 from __future__ import annotations
 
@@ -50,14 +51,12 @@ def framesig(signal: torch.Tensor, frame_len: int, frame_step: int, winfunc: Cal
 
 
 def _spec(frames: torch.Tensor, NFFT: int, power: bool) -> torch.Tensor:
-    if NFFT != 512:
-        raise AudioProcessingError(f"NFFT={NFFT} is not supported: the HIP transform is 512-point")
     if frames.dim() != 2:
         raise AudioProcessingError("expected frames of shape [num_frames, frame_len]")
     ctx = _ctx_for(frames)
     fr = _f32(frames)
     spec = torch.empty((fr.shape[0], NFFT // 2 + 1), dtype=torch.float32, device=frames.device)
-    ctx.spec512_f32(fr, power, spec)
+    ctx.spec_f32(fr, int(NFFT), power, spec)
     return spec.to(frames.dtype)
 
 

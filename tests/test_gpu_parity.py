@@ -179,12 +179,62 @@ def test_frontend_rejects_unsupported(native):
     c = native.Context(0)
     try:
         with pytest.raises(AudioProcessingError):
-            c.set_frontend(nfft=1024)
+            c.set_frontend(nfft=8192)                 # beyond the float64 kernel's LDS
         with pytest.raises(AudioProcessingError):
-            c.set_frontend(frame_len=600)
+            c.set_frontend(nfft=3000)                 # not a power of two and > 2048
+        with pytest.raises(AudioProcessingError):
+            c.set_frontend(nfilt=65)
         assert c.frontend_shape() == (99, 10)  # a refused configuration leaves the previous one intact
+        assert c.frontend_math() == native.FE_F32
     finally:
         c.close()
+
+
+PRECISE_TOL = 1e-5  # float64 front end: the float32 rounding of cepstra of magnitude <= 64 is 3.8e-6
+
+
+def test_mfcc_float64_frontend_matches_everywhere(native, dev, e2e_golden, sigproc_golden):
+    """KWS_FE_F64 (everything after framing in float64, as psf): every golden clip -- the clean tones and gated bursts on
+    which the float32 kernel needs its dynamic-range allowance included -- within 1e-5 of the oracle, no allowance; the
+    fused path with it agrees with the reference model's golden logits."""
+    c = make_ctx(native)
+    try:
+        c.set_frontend_math(native.FE_F64)
+        assert c.frontend_math() == native.FE_F64
+        clips = np.concatenate([e2e_golden["clips"], synth_clips(16, 0, "uniform"), synth_clips(16, 1, "gauss")])
+        got = gpu_mfcc(c, dev, clips)[:, 0]
+        want = np.stack([o_mfcc.extract_features_pcm16(x) for x in clips])
+        err = np.abs(got - want).max(axis=(1, 2))
+        assert err.max() <= PRECISE_TOL, (int(err.argmax()), float(err.max()))
+        assert np.all(got[0, :, 1:] == 0.0) and np.all(np.abs(got[0, :, 0] + 36.04365338911715) < 1e-5)   # all-zero clip
+        c.load_dscnn(e2e_golden["he.blob"], 12)
+        logits, labels = gpu_infer(c, dev, e2e_golden["clips"])
+        assert np.abs(logits - e2e_golden["he.logits"][8:]).max() <= 2e-5
+        assert np.array_equal(labels, e2e_golden["he.label"][8:])
+        x = torch.from_numpy(o_mfcc.pcm16_to_float(clips[:5])).to(dev)           # float32-signal entry point
+        out = torch.empty((5, 1, 99, 10), dtype=torch.float32, device=dev)
+        c.mfcc_f32(x, out)
+        c.sync()
+        assert np.array_equal(out.cpu().numpy()[:, 0], got[:5])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("winlen,nfft", [(0.04, 640), (0.064, 1024), (0.025, 512), (0.1, 1600)])
+def test_mfcc_other_transform_lengths(dev, winlen, nfft):
+    """extract_features with winlen * samplerate > 512: the reference then uses nfft = int(winlen * samplerate)
+    (audio_processor.py:268), e.g. 640 -- not a power of two (direct DFT), 1024 (FFT), 1600.  float64 kernel vs oracle."""
+    from kws.libs.audio_processor import AudioConfig, AudioProcessor
+
+    ap = AudioProcessor(None, AudioConfig(), precise=(nfft == 512))
+    clip = synth_clips(1, 40, "gauss")[0] if nfft != 1600 else synth_clips(1, 41, "uniform")[0]
+    clip[2000:2400] = 0
+    feat = ap.extract_features(o_mfcc.pcm16_to_float(clip), winlen=winlen)
+    spec = o_mfcc.FrontendSpec(winlen=winlen, nfft=max(512, int(winlen * 16000)))
+    assert spec.nfft == nfft
+    want = o_mfcc.mfcc(o_mfcc.pcm16_to_float(clip), spec)
+    assert feat.shape == want.shape == (spec.num_frames, 10)
+    assert np.abs(feat - want).max() <= PRECISE_TOL
 
 
 # ------------------------------------------------------------------------------------------- sigproc operators
@@ -205,6 +255,23 @@ def test_sigproc_operators_against_reference_golden(ctx, dev, sigproc_golden):
         assert np.abs(ps[keep] - ps_ref).max() <= 2e-6 * scale
         mag = sigproc.magspec(frames, 512).cpu().numpy().astype(np.float64)
         np.testing.assert_allclose(mag[keep] ** 2 / 512, ps_ref, atol=4e-6 * scale)
+
+
+@pytest.mark.parametrize("NFFT", [64, 256, 400, 640, 1024, 2048, 4096])
+def test_sigproc_any_nfft(dev, NFFT):
+    """magspec / powspec take any NFFT (sigproc.py:55-90): frames shorter than NFFT are zero-padded, longer ones truncated;
+    float64 transform behind a float32 boundary -> relative error of a float32 rounding."""
+    from kws.libs.speech_features import sigproc
+
+    rng = np.random.default_rng(NFFT)
+    frames = rng.standard_normal((7, 400))
+    fr = torch.from_numpy(frames).to(dev)
+    want = np.abs(np.fft.rfft(frames.astype(np.float32).astype(np.float64), NFFT))
+    mag = sigproc.magspec(fr, NFFT)
+    assert mag.dtype == torch.float64 and tuple(mag.shape) == (7, NFFT // 2 + 1)
+    assert np.abs(mag.cpu().numpy() - want).max() <= 2e-7 * want.max()
+    ps = sigproc.powspec(fr, NFFT).cpu().numpy()
+    assert np.abs(ps - want ** 2 / NFFT).max() <= 3e-7 * (want ** 2 / NFFT).max()
 
 
 def test_sigproc_reference_unit_test_recipe(dev, sigproc_golden):
