@@ -313,6 +313,17 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
             dct64[(size_t)i * nfilt + j] = lift * (i == 0 ? std::sqrt(1.0 / nfilt) : std::sqrt(2.0 / nfilt) * std::cos(pi * i * (2 * j + 1) / (2.0 * nfilt)));
     }
 
+    // per-bin mel weights exactly as psf's get_filterbanks forms them (float64 divisions): bin i in [e_j, e_j+1) rises in
+    // filter j with (i - e_j)/(e_j+1 - e_j) and falls in filter j-1 with (e_j+1 - i)/(e_j+1 - e_j)
+    const int nb64 = nfft / 2 + 1;
+    std::vector<double> melw(2 * (size_t)nb64, 0.0);
+    for (int j = 0; j <= nfilt; ++j)
+        for (int i = edges[j]; i < edges[j + 1]; ++i) {
+            const double width = (double)(edges[j + 1] - edges[j]);
+            melw[i] = (double)(i - edges[j]) / width;
+            melw[(size_t)nb64 + i] = (double)(edges[j + 1] - i) / width;
+        }
+
     // one device allocation, every table 256-byte aligned
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
@@ -320,7 +331,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
                  o_dct = al(o_g + sizeof(uint32_t) * 64), o_slot = al(o_dct + sizeof(float) * dct.size()),
                  o_seg = al(o_slot + sizeof(int) * (NFFT / 2)), o_tw64 = al(o_seg + sizeof(int) * 64),
                  o_edges = al(o_tw64 + sizeof(double) * tw64.size()), o_dct64 = al(o_edges + sizeof(int) * edges.size()),
-                 total = al(o_dct64 + sizeof(double) * dct64.size());
+                 o_melw = al(o_dct64 + sizeof(double) * dct64.size()), total = al(o_melw + sizeof(double) * melw.size());
     std::vector<unsigned char> host(total, 0);
     memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
     memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
@@ -333,6 +344,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     memcpy(&host[o_tw64], tw64.data(), sizeof(double) * tw64.size());
     memcpy(&host[o_edges], edges.data(), sizeof(int) * edges.size());
     memcpy(&host[o_dct64], dct64.data(), sizeof(double) * dct64.size());
+    memcpy(&host[o_melw], melw.data(), sizeof(double) * melw.size());
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
@@ -358,6 +370,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->ft.tw64 = reinterpret_cast<const double*>(b + o_tw64);
     c->ft.mel_edges = reinterpret_cast<const int*>(b + o_edges);
     c->ft.dct64 = reinterpret_cast<const double*>(b + o_dct64);
+    c->ft.mel_w64 = reinterpret_cast<const double*>(b + o_melw);
 
     FrontendParams& p = c->fp;
     p.n_samples = n_samples;

@@ -56,6 +56,7 @@ struct FrontendTables {
     // float64 kernel (kws_mfcc_f64.hip)
     const double* tw64;        // [nfft][2]  (cos, -sin)(2*pi*k/nfft)
     const int* mel_edges;      // [nfilt+2]  psf's bin edges
+    const double* mel_w64;     // [2][nfft/2+1]  per bin: its weight on the rising edge of its filter / on the falling edge of the one below
     const double* dct64;       // [numcep][nfilt]  DCT-II ortho x lifter
 };
 
