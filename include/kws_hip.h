@@ -115,6 +115,11 @@ int kws_mfcc_f32(kws_ctx* ctx, const float* d_wav, int B, float* d_out);
  * fc.bias), float32; n_floats must be 25664 + 65*num_classes.  Copied to the device; the caller
  * keeps ownership.  Replaces KeywordSpottingModel.load (models.py:55-72). */
 int kws_load_dscnn(kws_ctx* ctx, const float* blob, size_t n_floats, int num_classes);
+/* The same for DepthwiseSeparableConv(num_classes, input_channels) with input_channels > 1 (models.py:125,135):
+ * conv1.weight is then [64, input_channels, 10, 10], n_floats = 6400*input_channels + 19264 + 65*num_classes, and
+ * kws_forward_f32 takes d_feat float32 [B, input_channels, 99, 10]: conv1 runs in a general kernel and the fused kernel
+ * starts at block 1.  The wav -> label entry points need input_channels == 1 (an MFCC map has one channel). */
+int kws_load_dscnn_ex(kws_ctx* ctx, const float* blob, size_t n_floats, int num_classes, int input_channels);
 
 /* Forward on precomputed features.  d_feat: float32 [B,1,99,10]; d_logits: float32
  * [B,num_classes]; d_label: int32 [B] = argmax (first maximum wins, torch.max semantics,

@@ -416,25 +416,37 @@ int kws_frontend_shape(kws_ctx* c, int* num_frames, int* numcep) {
 }
 
 int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_classes) {
+    return kws_load_dscnn_ex(c, blob, n_floats, num_classes, 1);
+}
+
+int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_classes, int input_channels) {
     if (!c) return KWS_EINVAL;
     if (!blob) return fail(c, KWS_EINVAL, "kws_load_dscnn: blob is NULL");
     if (num_classes < 1 || num_classes > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_load_dscnn: num_classes must be in [1, 64]");
-    const size_t expect = 6400 + 64 + 4 * (576 + 64 + 4096 + 64) + (size_t)num_classes * 64 + num_classes;
+    if (input_channels < 1 || input_channels > 64) return fail(c, KWS_EUNSUPPORTED, "kws_load_dscnn: input_channels must be in [1, 64]");
+    const size_t c1_floats = (size_t)6400 * input_channels;
+    const size_t expect = c1_floats + 64 + 4 * (576 + 64 + 4096 + 64) + (size_t)num_classes * 64 + num_classes;
     if (n_floats != expect) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "kws_load_dscnn: expected %zu floats for %d classes, got %zu", expect, num_classes, n_floats);
+        char msg[200];
+        snprintf(msg, sizeof msg, "kws_load_dscnn: expected %zu floats for %d classes and %d input channel(s), got %zu", expect,
+                 num_classes, input_channels, n_floats);
         return fail(c, KWS_EINVAL, msg);
     }
-    // repack: c1_w [100][64] | c1_b [64] | dw [4][64][12] | pw_w [4][cin][cout] | pw_b [4][64] | fc_w | fc_b
+    // repack: c1_w [100][64] | c1_b [64] | dw [4][64][12] | pw_w [4][cin][cout] | pw_b [4][64] | fc_w | fc_b | splits |
+    // (input_channels > 1) conv1 as [ci][tap][cout] for kws_conv1_general_kernel
     const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
                  o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64,
                  o_split = (o_fcb + num_classes + 3) & ~(size_t)3, o_c1s = o_split + 4 * 2 * 4 * 3 * 64 * 4,
-                 total = o_c1s + 2 * 7 * 3 * 64 * 4;
+                 o_c1g = o_c1s + 2 * 7 * 3 * 64 * 4, total = o_c1g + (input_channels > 1 ? c1_floats : 0);
     std::vector<float> h(total, 0.f);
     const float* src = blob;
-    for (int co = 0; co < 64; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
+    if (input_channels > 1)  // conv1.weight [64][C][10][10] -> [ci][tap][cout]
+        for (int co = 0; co < 64; ++co)
+            for (int ci = 0; ci < input_channels; ++ci)
+                for (int k = 0; k < 100; ++k) h[o_c1g + ((size_t)ci * 100 + k) * 64 + co] = src[((size_t)co * input_channels + ci) * 100 + k];
+    for (int co = 0; co < 64 && input_channels == 1; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
         for (int k = 0; k < 100; ++k) h[o_c1w + (size_t)k * 64 + co] = src[co * 100 + k];
-    {
+    if (input_channels == 1) {
         // conv1 as bf16x3 MFMA A operands (32x32x16).  The 100 taps are split between the half-waves: lanes
         // 32..63 take kernel rows 5..9, so both halves walk the same 50 (+6 zero) offsets f = 10*(kh%5) + kw and
         // their LDS addresses differ by a constant.  Lane l of (ct, kb): cout = 32ct + (l&31), f = 8kb + j.
@@ -456,7 +468,7 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
                         }
                     }
     }
-    src += 6400;
+    src += c1_floats;
     memcpy(&h[o_c1b], src, 64 * sizeof(float));
     src += 64;
     for (int b = 0; b < 4; ++b) {
@@ -517,6 +529,8 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     c->mw.fc_w = d + o_fcw;
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
+    c->mw.in_channels = input_channels;
+    c->mw.c1_general = input_channels > 1 ? d + o_c1g : nullptr;
     c->model_ready = true;
     return KWS_OK;
 }
@@ -579,6 +593,8 @@ int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
     return KWS_OK;
 }
 
+static int grow_conv_ws(kws_ctx* c, size_t need, const std::string& fn);
+
 static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                         int mode, const char* fn, unsigned long long* d_stamps = nullptr) {
     int rc = check_batch(c, d_feat, B, fn);
@@ -586,6 +602,18 @@ static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits,
     if (!d_logits) return fail(c, KWS_EINVAL, std::string(fn) + ": d_logits is NULL");
     if (!c->model_ready) return fail(c, KWS_ESTATE, std::string(fn) + ": no model loaded (kws_load_dscnn)");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->mw.in_channels > 1) {
+        // multi-channel input (models.py:125,135): conv1 in its own kernel through the context scratch, then the fused
+        // kernel from block 1 on; the diagnostics variants exist for the single-channel model only
+        if (d_act || d_stamps || mode != KWS_PW_SPLIT_BF16)
+            return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": input_channels > 1 runs on the split-bf16 product kernel only");
+        rc = grow_conv_ws(c, (size_t)B * 64 * 141, fn);
+        if (rc) return rc;
+        HIP_TRY(c, launch_conv1_general(c->stream, d_feat, B, c->mw.in_channels, c->mw.c1_general, c->mw.c1_b, c->d_conv_ws));
+        ProfScope ps(c, KWS_K_DSCNN);
+        HIP_TRY(c, launch_dscnn(c->stream, c->mw, c->d_conv_ws, B, d_logits, d_label, nullptr, mode, nullptr, nullptr, true));
+        return KWS_OK;
+    }
     ProfScope ps(c, KWS_K_DSCNN);
     HIP_TRY(c, launch_dscnn(c->stream, c->mw, d_feat, B, d_logits, d_label, d_act, mode, d_stamps));
     return KWS_OK;
@@ -626,6 +654,7 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     int rc = check_batch(c, d_wav, B, "kws_infer_i16");
     if (rc) return rc;
     if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_i16: front end or model not configured");
+    if (c->mw.in_channels != 1) return fail(c, KWS_EUNSUPPORTED, "kws_infer_i16: the MFCC front end yields one channel; the model was loaded with more");
     if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
         return fail(c, KWS_EUNSUPPORTED, "kws_infer_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
     rc = kws_reserve(c, B);
@@ -802,12 +831,12 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
 }
 
 // Grow the context's float scratch (convolution outputs between two kernels of one call) to at least `need` floats.
-static int grow_conv_ws(kws_ctx* c, size_t need, const char* fn) {
+static int grow_conv_ws(kws_ctx* c, size_t need, const std::string& fn) {
     if (need <= c->conv_ws_floats) return KWS_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     float* d = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d), need * sizeof(float)) != hipSuccess)
-        return fail(c, KWS_ENOMEM, std::string(fn) + ": workspace allocation failed");
+        return fail(c, KWS_ENOMEM, fn + ": workspace allocation failed");
     if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
     c->d_conv_ws = d;
     c->conv_ws_floats = need;
@@ -968,6 +997,7 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
     if (!d_hop) return fail(c, KWS_EINVAL, "kws_stream_push_i16: d_hop is NULL");
     if (d_logits) {
         if (!c->model_ready) return fail(c, KWS_ESTATE, "kws_stream_push_i16: no model loaded (kws_load_dscnn)");
+        if (c->mw.in_channels != 1) return fail(c, KWS_EUNSUPPORTED, "kws_stream_push_i16: the model was loaded with more than one input channel");
         if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
             return fail(c, KWS_EUNSUPPORTED, "kws_stream_push_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
     }

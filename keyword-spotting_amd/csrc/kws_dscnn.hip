@@ -665,7 +665,9 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 
 // DIAG = false: the product instantiation -- no activation dump, no stamps (their pointers and loops cost
 // registers and 5 KB of code even when unused).
-template <int MODE, bool DIAG = true>
+// PRECONV: `feat` is not the MFCC map but conv1's output [B][64][47*3] (ReLU applied), computed by kws_conv1_general_kernel
+// for a model with input_channels > 1 (models.py:125,135); the kernel then starts at block 1.
+template <int MODE, bool DIAG = true, bool PRECONV = false>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
                                                            float* __restrict__ act_arg,
@@ -692,10 +694,25 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 2] = __builtin_amdgcn_s_memrealtime();
     stamp();  // 0: start
 
+    constexpr bool SPLIT = MODE >= 4;
+    PwOperands<MODE> wa;            // pointwise operands of the running block
+    if constexpr (PRECONV) {
+        static_assert(!PRECONV || MODE >= 4, "the pre-convolved entry exists for the product (split) path only");
+        const float* z = feat + (size_t)clip * (CH * P0);
+        BlockTables t1;
+        fetch_block_tables(w, 1, tid, t1);
+        for (int i = tid; i < CH * P0; i += NT) lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)] = z[i];
+        if (tid < CH) {
+            lds[OFF_Z0 + pidx(tid, P0, P0 + 2)] = 0.f;
+            lds[OFF_Z0 + pidx(tid, P0 + 1, P0 + 2)] = 0.f;
+        }
+        store_block_tables(lds, 1, tid, t1);
+        load_block_head(w, 1, lane, wa);
+        stamp();  // 1
+    } else {
     // ---- phase 0: MFCC map -> zero-padded [103][14] in LDS, weight loads in flight --------------------
     // The feature map and block 1's tables are on the critical path of this phase: their loads are issued first
     // (vector memory returns in order), the conv1 operands behind them.
-    constexpr bool SPLIT = MODE >= 4;
     float* featp = lds + OFF_FEAT;
     const float* f = feat + (size_t)clip * (IN_T * IN_F);
     constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
@@ -713,7 +730,6 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     __builtin_amdgcn_sched_barrier(0);
     float a1[SPLIT ? 1 : 50];       // conv1 weights of this wave's output-channel tile (f32 MFMA A operands)
     uintx4 c1f[SPLIT ? 7 : 1][3];   // the same as bf16 pieces (split path)
-    PwOperands<MODE> wa;            // pointwise operands of the running block
     if constexpr (SPLIT) {
         const uintx4* src = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(wv & 1) * (7 * 3 * 64) + lane;
 #pragma unroll
@@ -743,6 +759,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         load_block_head(w, 1, lane, wa);  // the conv1 operands are dead: block 1's first fly across the barrier
     } else {
         conv1_phase<MFMA>(w, lds, tid, a1);
+    }
     }
     stamp();  // 2: conv1 units of wave 0 done
     __syncthreads();
@@ -854,7 +871,8 @@ hipError_t dscnn_init_device() {
     const void* kernels[] = {reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<0>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<1>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, true>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -862,10 +880,62 @@ hipError_t dscnn_init_device() {
     return hipSuccess;
 }
 
+// conv1 for input_channels > 1 (reference kws/libs/models.py:125,135: Conv2d(input_channels, 64, 10, stride 2, padding 2)):
+// one 512-thread workgroup per clip; thread (co = tid & 63, group g = tid >> 6) owns output channel co at positions
+// g, g + 8, ...; per input channel the zero-padded plane goes through LDS (every lane of a wavefront reads the same
+// address: a broadcast) and the 100 taps come from a [ci][tap][co] weight image (coalesced).  ReLU(bias + sum) -> [64][141].
+namespace {
+__global__ __launch_bounds__(NT) void kws_conv1_general_kernel(const float* __restrict__ x, int C_in, const float* __restrict__ wt,
+                                                               const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float plane[FEAT_H * FEAT_W];
+    const int tid = threadIdx.x, co = tid & 63, g = tid >> 6;
+    constexpr int PER = (P0 + NW - 1) / NW;  // positions per thread
+    float acc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) acc[k] = 0.f;
+    const float* xc = x + (size_t)blockIdx.x * C_in * (IN_T * IN_F);
+    for (int ci = 0; ci < C_in; ++ci) {
+        __syncthreads();
+        for (int i = tid; i < FEAT_H * FEAT_W; i += NT) {
+            const int r = i / FEAT_W - 2, cidx = i % FEAT_W - 2;
+            plane[i] = ((unsigned)r < (unsigned)IN_T && (unsigned)cidx < (unsigned)IN_F) ? xc[(size_t)ci * (IN_T * IN_F) + r * IN_F + cidx] : 0.f;
+        }
+        __syncthreads();
+        const float* wc = wt + (size_t)ci * (C1_K * C1_K) * CH + co;
+        for (int tap = 0; tap < C1_K * C1_K; ++tap) {
+            const float wv_ = wc[(size_t)tap * CH];
+            const int kh = tap / C1_K, kw = tap % C1_K;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int pos = g + NW * k;
+                if (pos < P0) acc[k] = fmaf(wv_, plane[(2 * (pos / C1_W) + kh) * FEAT_W + 2 * (pos % C1_W) + kw], acc[k]);
+            }
+        }
+    }
+    float* o = out + (size_t)blockIdx.x * (CH * P0) + (size_t)co * P0;
+    const float bv = bias[co];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pos = g + NW * k;
+        if (pos < P0) o[pos] = relu(acc[k] + bv);
+    }
+}
+}  // namespace
+
+hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in, const float* d_wt, const float* d_bias, float* d_out) {
+    hipLaunchKernelGGL(kws_conv1_general_kernel, dim3(B), dim3(NT), 0, s, d_x, C_in, d_wt, d_bias, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
-                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps, const int* d_ring_hops) {
+                        int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps, const int* d_ring_hops,
+                        bool preconv) {
     const size_t lds = LDS_FLOATS * sizeof(float);
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
+    if (preconv) {  // d_feat = conv1 output of a multi-channel model (kws_conv1_general_kernel): product path only
+        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr);
+        return hipGetLastError();
+    }
     // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /
     // stencil only; wrong results by construction, reachable only through the diagnostics entry point)
     switch (mode) {

@@ -119,12 +119,16 @@ struct DscnnWeights {
     const float* fc_w;     // [C][64]
     const float* fc_b;     // [C]
     int num_classes;
+    int in_channels;           // 1: the fused kernel computes conv1 itself; > 1: kws_conv1_general_kernel + the PRECONV entry
+    const float* c1_general;   // [ci][100][64]  conv1 weights of a multi-channel model (in_channels > 1), else NULL
 };
 
 hipError_t dscnn_init_device();
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
-                        const int* d_ring_hops = nullptr);
+                        const int* d_ring_hops = nullptr, bool preconv = false);
+// conv1 of a model with input_channels > 1: x [B][C_in][99][10] -> relu(conv1) [B][64][141]; d_wt = weights as [ci][tap][co]
+hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in, const float* d_wt, const float* d_bias, float* d_out);
 
 // ------------------------------------------------------------------------------------------------
 // cnn-trad-fpool3 (build-defined model-zoo member, kws_cnntrad.hip)

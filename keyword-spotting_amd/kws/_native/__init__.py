@@ -44,6 +44,7 @@ SIGNATURES = {
     "kws_mfcc_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p]),
     "kws_mfcc_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p]),
     "kws_load_dscnn": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
+    "kws_load_dscnn_ex": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int]),
     "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_dsblock_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
@@ -182,10 +183,11 @@ class Context:
         self._check(self._lib.kws_mfcc_f32(self._h, _ptr(wav), int(wav.shape[0]), _ptr(out)), AudioProcessingError)
 
     # -- model ----------------------------------------------------------------------------------
-    def load_dscnn(self, blob: np.ndarray, num_classes: int):
+    def load_dscnn(self, blob: np.ndarray, num_classes: int, input_channels: int = 1):
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         self._check(
-            self._lib.kws_load_dscnn(self._h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, int(num_classes)),
+            self._lib.kws_load_dscnn_ex(self._h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, int(num_classes),
+                                        int(input_channels)),
             ModelError,
         )
         self.num_classes = int(num_classes)

@@ -107,8 +107,9 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
 
     def __init__(self, num_classes: int = 12, input_channels: int = 1):
         super().__init__(num_classes)
-        if input_channels != 1:
-            raise ModelError("the fused kernel is built for input_channels=1 (mono MFCC map)")
+        if not 1 <= input_channels <= 64:
+            raise ModelError("input_channels must be in [1, 64]")
+        self.input_channels = int(input_channels)
         self.conv1 = nn.Conv2d(input_channels, 64, kernel_size=10, stride=2, padding=2)
         self.dsconv1 = DepthwiseSeparableConvBlock(64, 64)
         self.dsconv2 = DepthwiseSeparableConvBlock(64, 64)
@@ -150,7 +151,7 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
             self._uploaded = None
         fp = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if fp != self._uploaded:
-            self._ctx.load_dscnn(self.packed_weights(), self.num_classes)
+            self._ctx.load_dscnn(self.packed_weights(), self.num_classes, self.input_channels)
             self._uploaded = fp
         self._ctx.use_torch_stream()
         return self._ctx
@@ -162,8 +163,8 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
     def forward(self, x: torch.Tensor, return_labels: bool = False):
         """``float32[B,1,99,10]`` on the GPU -> logits ``float32[B,num_classes]`` (and argmax labels)."""
         self._check_input(x, "DepthwiseSeparableConv.forward")
-        if x.dim() != 4 or tuple(x.shape[1:]) != FEATURE_SHAPE:
-            raise ModelError(f"expected input [B,1,99,10], got {tuple(x.shape)}")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.input_channels,) + FEATURE_SHAPE[1:]:
+            raise ModelError(f"expected input [B,{self.input_channels},99,10], got {tuple(x.shape)}")
         ctx = self._context(x.device.index or 0)
         x = x.detach().to(torch.float32).contiguous()
         logits = torch.empty((x.shape[0], self.num_classes), dtype=torch.float32, device=x.device)
@@ -175,6 +176,8 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
         """Fused path: ``int16[B,16000]`` PCM on the GPU -> (logits, labels); MFCC + DS-CNN back to back
         on one stream, features never leave the device (``kws_infer_i16``)."""
         self._check_input(wav, "DepthwiseSeparableConv.infer_pcm16")
+        if self.input_channels != 1:
+            raise ModelError("infer_pcm16 needs input_channels=1: the MFCC front end yields one channel")
         if wav.dtype != torch.int16 or wav.dim() != 2:
             raise ModelError("infer_pcm16 expects an int16 tensor [B, n_samples]")
         ctx = self._context(wav.device.index or 0)

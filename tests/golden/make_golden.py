@@ -10,6 +10,7 @@ Writes (data only -- inputs and expected outputs, no reference source):
   tests/golden/dscnn_golden.npz     seeded state_dicts + inputs -> reference
                                     DepthwiseSeparableConv logits, per-layer probes
   tests/golden/dsblock_golden.npz   DepthwiseSeparableConvBlock on its own: four shapes -> reference outputs
+  tests/golden/multichannel_golden.npz  DepthwiseSeparableConv(input_channels=3) on six 3-channel maps -> reference logits
   tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
                                     reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
                                     AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
@@ -301,8 +302,40 @@ def dsblock_golden():
     np.savez_compressed(os.path.join(HERE, "dsblock_golden.npz"), **save)
 
 
+def multichannel_golden():
+    """DepthwiseSeparableConv(num_classes=12, input_channels=3) (kws/libs/models.py:125,135), imported and run on
+    3-channel maps; weights scaled like the 'he' tag so the logits follow the input."""
+    rs = np.random.RandomState(21)
+    ref = ref_models.DepthwiseSeparableConv(num_classes=12, input_channels=3).eval()
+    st = {}
+    for k, v in ref.state_dict().items():
+        shp = tuple(v.shape)
+        if k.endswith("bias"):
+            w = rs.standard_normal(shp) * 0.1
+        elif k.startswith("fc"):
+            w = rs.standard_normal(shp) * 0.5
+        else:
+            w = rs.standard_normal(shp) * np.sqrt(2.0 / int(np.prod(shp[1:])))
+        st[k] = torch.from_numpy(w.astype(np.float32))
+    ref.load_state_dict(st)
+    x = torch.from_numpy((rs.standard_normal((6, 1, 1, 1)) * 3.0 * rs.standard_normal((6, 3, 99, 10))).astype(np.float32))
+    x[1] = 0.0
+    with torch.no_grad():
+        st["fc.bias"] = (st["fc.bias"] - ref(x).mean(0)).float()    # classes balanced over the inputs, as in the 'he' tag
+        ref.load_state_dict(st)
+        logits = ref(x)
+        conv1 = torch.relu(ref.conv1(x))
+    assert len(set(torch.max(logits, 1)[1].tolist())) >= 3
+    blob = np.concatenate([st[k].reshape(-1).numpy() for k in ref.state_dict().keys()])
+    assert blob.size == 6400 * 3 + 19264 + 65 * 12
+    np.savez_compressed(os.path.join(HERE, "multichannel_golden.npz"), x=x.numpy(), blob=blob, logits=logits.numpy(),
+                        label=torch.max(logits, 1)[1].numpy(), conv1=conv1[:2].numpy())
+    print("multichannel: logits std across inputs", float(logits.std(0).mean()), "labels", torch.max(logits, 1)[1].tolist())
+
+
 if __name__ == "__main__":
     sigproc_golden()
     dscnn_golden()
     e2e_golden()
     dsblock_golden()
+    multichannel_golden()

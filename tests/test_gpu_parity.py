@@ -4,6 +4,8 @@ Tolerances (BASELINE.json north_star): logits within 1e-4 of the CPU reference p
 identical; MFCC within 1e-4 (float32 kernel vs float64 psf arithmetic); integer/bit-level pieces
 (PCM scaling + pre-emphasis, labels, run-to-run determinism) exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -403,6 +405,32 @@ def test_standalone_block_forward(dev, dsblock_golden):
         blk(torch.zeros(1, 3, 4, 4))                       # CPU tensor: no fallback
     with pytest.raises(ModelError):
         blk(torch.zeros(1, 4, 4, 4, device=dev))           # wrong channel count
+
+
+def test_multichannel_model(dev):
+    """DepthwiseSeparableConv(input_channels=3) (models.py:125,135): conv1 over three channels in the general kernel, then
+    the fused kernel from block 1; logits and labels against the imported reference module's (golden)."""
+    from kws.common.errors import ModelError
+    from kws.libs.models import DepthwiseSeparableConv
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multichannel_golden.npz"))
+    m = DepthwiseSeparableConv(num_classes=12, input_channels=3)
+    state, off = {}, 0
+    for k, v in m.state_dict().items():
+        n = v.numel()
+        state[k] = torch.from_numpy(g["blob"][off:off + n].reshape(tuple(v.shape)).copy())
+        off += n
+    assert off == g["blob"].size
+    m.load_state_dict(state)
+    logits, labels = m.forward(torch.from_numpy(g["x"]).to(dev), return_labels=True)
+    err = float(np.abs(logits.cpu().numpy() - g["logits"]).max())
+    assert err <= min(TOL, 4 * LAYER_RTOL * float(np.abs(g["logits"]).max())), err
+    assert np.array_equal(labels.cpu().numpy(), g["label"])
+    assert float(g["logits"].std(axis=0).mean()) >= 0.1
+    with pytest.raises(ModelError):
+        m.forward(torch.zeros(2, 1, 99, 10, device=dev))            # wrong channel count
+    with pytest.raises(ModelError):
+        m.infer_pcm16(torch.zeros(2, 16000, dtype=torch.int16, device=dev))   # an MFCC map has one channel
 
 
 def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
