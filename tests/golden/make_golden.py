@@ -10,7 +10,7 @@ Writes (data only -- inputs and expected outputs, no reference source):
   tests/golden/dscnn_golden.npz     seeded state_dicts + inputs -> reference
                                     DepthwiseSeparableConv logits, per-layer probes
   tests/golden/dsblock_golden.npz   DepthwiseSeparableConvBlock on its own: four shapes -> reference outputs
-  tests/golden/multichannel_golden.npz  DepthwiseSeparableConv(input_channels=3) on six 3-channel maps -> reference logits
+  tests/golden/multichannel_golden.npz  DepthwiseSeparableConv(input_channels=3) on ten 3-channel maps -> reference logits
   tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
                                     reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
                                     AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
@@ -318,8 +318,9 @@ def multichannel_golden():
             w = rs.standard_normal(shp) * np.sqrt(2.0 / int(np.prod(shp[1:])))
         st[k] = torch.from_numpy(w.astype(np.float32))
     ref.load_state_dict(st)
-    x = torch.from_numpy((rs.standard_normal((6, 1, 1, 1)) * 3.0 * rs.standard_normal((6, 3, 99, 10))).astype(np.float32))
-    x[1] = 0.0
+    x = rs.standard_normal((10, 3, 99, 10)) * np.array([0.2, 0.0, 1, 2, 4, 8, 3, 3, 3, 3]).reshape(-1, 1, 1, 1)
+    x[6, 0] = 0; x[7, 1] = 0; x[8, 2] = 0; x[9] += 5.0           # a silent channel each, and an offset
+    x = torch.from_numpy(x.astype(np.float32))
     with torch.no_grad():
         st["fc.bias"] = (st["fc.bias"] - ref(x).mean(0)).float()    # classes balanced over the inputs, as in the 'he' tag
         ref.load_state_dict(st)
