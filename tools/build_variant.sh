@@ -9,7 +9,7 @@ SRC=$ROOT/keyword-spotting_amd/csrc
 OBJ=$ROOT/tools/bin/obj_$NAME
 mkdir -p "$OBJ"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wall -Wno-unused-function -fvisibility=hidden -ffp-contract=off -DKWS_BUILD $*"
-for f in kws_api kws_ingest kws_dsblock kws_mfcc kws_dscnn kws_cnntrad; do
+for f in kws_api kws_ingest kws_dsblock kws_mfcc kws_mfcc_f64 kws_dscnn kws_cnntrad; do
   # only the translation units a macro can touch are rebuilt per variant; the others are linked from the main build
   if [ "$f" != kws_api ] && [ -f "$SRC/build/$f.o" ] && ! grep -q "KWS_MFCC_\|KWS_DSCNN_\|KWS_X_" "$SRC/$f.hip"; then cp "$SRC/build/$f.o" "$OBJ/$f.o"; continue; fi
   /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
