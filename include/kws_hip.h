@@ -141,6 +141,10 @@ int kws_dsblock_forward_f32(kws_ctx* ctx, const float* d_x, int B, int C_in, int
  * shape of inference(wav) -> label (kws/inference/inference_local.py:67-81), batched. */
 int kws_infer_i16(kws_ctx* ctx, const int16_t* d_wav, int B, float* d_logits, int32_t* d_label);
 
+/* The same for float32 signals in [-1, 1] (d_wav float32 [B, n_samples]): what librosa.load hands the reference for files
+ * that are not 16-bit PCM (24-bit, float, stereo mixed down in float: audio_processor.py:145). */
+int kws_infer_f32(kws_ctx* ctx, const float* d_wav, int B, float* d_logits, int32_t* d_label);
+
 /* The same from HOST memory to HOST memory -- what the reference does between the decoded audio and the model input:
  * DataLoader workers collate batches into pinned memory and the trainer calls inputs.to(device)
  * (kws/libs/data_loader.py:96-105, train.py:108-121, kws/libs/training.py:286).  h_wav: int16 [B, n_samples] in host

@@ -664,6 +664,20 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, c->pw_math, "kws_infer_i16");
 }
 
+int kws_infer_f32(kws_ctx* c, const float* d_wav, int B, float* d_logits, int32_t* d_label) {
+    int rc = check_batch(c, d_wav, B, "kws_infer_f32");
+    if (rc) return rc;
+    if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_f32: front end or model not configured");
+    if (c->mw.in_channels != 1) return fail(c, KWS_EUNSUPPORTED, "kws_infer_f32: the MFCC front end yields one channel; the model was loaded with more");
+    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
+        return fail(c, KWS_EUNSUPPORTED, "kws_infer_f32: the DS-CNN kernel is built for a 99 x 10 feature map");
+    rc = kws_reserve(c, B);
+    if (rc) return rc;
+    rc = kws_mfcc_f32(c, d_wav, B, c->d_feat_ws);
+    if (rc) return rc;
+    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, c->pw_math, "kws_infer_f32");
+}
+
 // ---- streaming ------------------------------------------------------------------------------------
 static void smooth_free(kws_ctx* c) {
     if (c->d_post_ring) (void)hipFree(c->d_post_ring);

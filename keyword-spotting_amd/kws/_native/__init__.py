@@ -49,6 +49,7 @@ SIGNATURES = {
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_dsblock_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _f32p]),
+    "kws_infer_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_host_i16": (C.c_int, [_c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "kws_ingest_config": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_int]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
@@ -273,6 +274,12 @@ class Context:
 
     def ingest_config(self, chunk_clips: int = 0, n_slots: int = 0, pack_threads: int = 0):
         self._check(self._lib.kws_ingest_config(self._h, int(chunk_clips), int(n_slots), int(pack_threads)), ModelError)
+
+    def infer_f32(self, wav, logits, label=None):
+        self._check(
+            self._lib.kws_infer_f32(self._h, _ptr(wav), int(wav.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
+            ModelError,
+        )
 
     # -- streaming -------------------------------------------------------------------------------
     def stream_open(self, n_streams: int):

@@ -10,7 +10,7 @@ import torch
 
 from kws.common.errors import ModelError
 from kws.datasets.speech_commands import DEFAULT_WORDS, SpeechCommandDataset
-from kws.libs.audio_processor import AudioConfig, fix_length, load_pcm16
+from kws.libs.audio_processor import AudioConfig, fix_length, load_audio, load_pcm16
 from kws.libs.models import DepthwiseSeparableConv
 
 WANTED_WORDS = [SpeechCommandDataset.SILENCE_LABEL, SpeechCommandDataset.UNKNOWN_LABEL] + DEFAULT_WORDS
@@ -58,15 +58,37 @@ class KeywordSpotter:
             logits, labels = ctx.infer_host_i16(src)
             yield labels, logits
 
-    def infer_files(self, paths: Sequence[str]) -> List[Tuple[int, str]]:
-        clips = []
+    def infer_files(self, paths: Sequence[str], resample: bool = False) -> List[Tuple[int, str]]:
+        """wav files -> (index, word).  16-bit mono files at the configured rate go through the int16 path (the PCM
+        itself is the device input); anything else -- other bit depths, float, stereo, and with ``resample=True`` other
+        rates -- is decoded to float32 mono as ``librosa.load`` does and takes the float32 path (``kws_infer_f32``)."""
+        n = self.config.desired_samples
+        clips, all_i16 = [], True
         for p in paths:
-            x = load_pcm16(p, self.config.sample_rate)
-            if x.ndim == 2:
-                x = x.astype(np.int32).mean(axis=1).astype(np.int16)
-            clips.append(fix_length(x, self.config.desired_samples))
-        labels, _ = self.infer_pcm16(np.stack(clips))
+            try:
+                x = load_pcm16(p, self.config.sample_rate)
+                if x.ndim == 2:
+                    raise ValueError("stereo: mix down in float")
+            except Exception:
+                x = load_audio(p, self.config.sample_rate, resample)
+                all_i16 = False
+            clips.append(fix_length(x, n))
+        if all_i16:
+            labels, _ = self.infer_pcm16(np.stack(clips))
+        else:
+            f32 = np.stack([c.astype(np.float32) / np.float32(32768.0) if c.dtype == np.int16 else c for c in clips])
+            labels, _ = self.infer_f32(f32)
         return [(int(i), self.words[int(i)]) for i in labels]
+
+    def infer_f32(self, signals: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """``float32[B,n]`` host signals in [-1, 1] -> (labels int32[B], logits float32[B,C]) (``kws_infer_f32``)."""
+        x = torch.from_numpy(np.ascontiguousarray(fix_length(np.atleast_2d(np.asarray(signals, dtype=np.float32)),
+                                                             self.config.desired_samples))).to(self.device)
+        ctx = self.model._context(self.device.index or 0)
+        logits = torch.empty((x.shape[0], self.model.num_classes), dtype=torch.float32, device=self.device)
+        labels = torch.empty((x.shape[0],), dtype=torch.int32, device=self.device)
+        ctx.infer_f32(x, logits, labels)
+        return labels.cpu().numpy(), logits.cpu().numpy()
 
 
 _default: Optional[KeywordSpotter] = None

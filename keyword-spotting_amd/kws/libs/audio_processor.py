@@ -7,7 +7,8 @@ delegates to ``python_speech_features.mfcc`` runs in the batched HIP kernel behi
 ``kws_mfcc_f32`` (include/kws_hip.h).  WAV decoding and the random augmentations stay on the host.
 
 Additions for batched use: ``extract_features_batch`` (device tensor in, ``float32[B,1,T,F]`` out --
-the collated batch of the reference's data loader) and ``load_pcm16``.
+the collated batch of the reference's data loader), ``load_pcm16`` (16-bit files as int16, the fast path's input) and
+``load_audio`` (any PCM / float WAV as float32 mono, what ``librosa.load`` returns).
 """
 from __future__ import annotations
 
@@ -78,6 +79,70 @@ def load_pcm16(path, sample_rate: int = 16000) -> np.ndarray:
     return data
 
 
+def load_audio(path, sample_rate: int = 16000, resample: bool = False) -> np.ndarray:
+    """Decode a WAV file to what ``librosa.load(path, sr=sample_rate)`` hands the reference (``audio_processor.py:145``):
+    float32 mono in [-1, 1).  Integer PCM of 8 / 16 / 24 / 32 bits is scaled like libsndfile does (u8: (v - 128)/128,
+    otherwise v / 2**(bits-1)), IEEE float32 / float64 is taken as is, WAVE_FORMAT_EXTENSIBLE is read through its
+    sub-format; channels are averaged in float32 (``librosa.to_mono``).
+
+    A file at another sample rate is refused unless ``resample=True``: librosa resamples with soxr ('soxr_hq'), which is
+    not available here and cannot be reproduced bit for bit; with ``resample=True`` a Kaiser-windowed polyphase filter
+    (``scipy.signal.resample_poly``) is used instead -- PARITY UNPINNED against the reference for such files."""
+    import struct
+
+    with open(str(path), "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise AudioProcessingError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            payload = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None or len(fmt) < 16:
+        raise AudioProcessingError(f"{path}: missing fmt or data chunk")
+    tag, ch, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:  # WAVE_FORMAT_EXTENSIBLE: the first two bytes of the sub-format GUID are the real tag
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    if ch < 1:
+        raise AudioProcessingError(f"{path}: no channels")
+    if tag == 1 and bits == 8:
+        x = (np.frombuffer(payload, dtype=np.uint8).astype(np.float32) - np.float32(128.0)) / np.float32(128.0)
+    elif tag == 1 and bits == 16:
+        x = np.frombuffer(payload[: len(payload) // 2 * 2], dtype="<i2").astype(np.float32) / np.float32(32768.0)
+    elif tag == 1 and bits == 24:
+        raw = np.frombuffer(payload[: len(payload) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+        v = np.where(v & 0x800000, v - (1 << 24), v)
+        x = v.astype(np.float32) / np.float32(8388608.0)
+    elif tag == 1 and bits == 32:
+        x = (np.frombuffer(payload[: len(payload) // 4 * 4], dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(payload[: len(payload) // 4 * 4], dtype="<f4").astype(np.float32)
+    elif tag == 3 and bits == 64:
+        x = np.frombuffer(payload[: len(payload) // 8 * 8], dtype="<f8").astype(np.float32)
+    else:
+        raise AudioProcessingError(f"{path}: unsupported WAV encoding (format tag {tag}, {bits} bits)")
+    x = x[: len(x) // ch * ch]
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1, dtype=np.float32)
+    if rate != sample_rate:
+        if not resample:
+            raise AudioProcessingError(f"{path}: sample rate {rate} != {sample_rate}; pass resample=True for a polyphase "
+                                       "resampler (librosa's soxr resampler cannot be reproduced: parity unpinned)")
+        from math import gcd
+
+        from scipy.signal import resample_poly
+
+        g = gcd(int(rate), int(sample_rate))
+        x = resample_poly(x.astype(np.float64), sample_rate // g, rate // g, window=("kaiser", 14.0)).astype(np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
 def _to_float_mono(pcm: np.ndarray) -> np.ndarray:
     x = pcm.astype(np.float32) / np.float32(32768.0)
     return x.mean(axis=1, dtype=np.float32) if x.ndim == 2 else x
@@ -95,7 +160,7 @@ class AudioProcessor:
     """WAV -> fixed length -> (augment) -> MFCC, with the MFCC on the GPU."""
 
     def __init__(self, dataset_path: Optional[Path], config: Optional[AudioConfig] = None, device: int = 0,
-                 precise: bool = False):
+                 precise: bool = False, resample: bool = False):
         """``precise=True`` selects the float64 front end (``KWS_FE_F64``: everything after framing in float64, as psf
         computes it) instead of the fast float32 kernel; geometries the fast kernel is not built for (``nfft != 512``,
         i.e. ``frame_length * sample_rate > 512``) use it anyway."""
@@ -103,6 +168,7 @@ class AudioProcessor:
         self.dataset_path = Path(dataset_path) if dataset_path is not None else None
         self.device = device
         self.precise = bool(precise)
+        self.resample = bool(resample)  # files at another rate: polyphase resampler instead of a refusal (parity unpinned)
         self._ctx = None
         self._ctx_key = None
         try:
@@ -120,7 +186,7 @@ class AudioProcessor:
         clips = []
         for wav_path in sorted(folder.glob("*.wav")):
             try:
-                clips.append(_to_float_mono(load_pcm16(wav_path, self.config.sample_rate)))
+                clips.append(load_audio(wav_path, self.config.sample_rate, self.resample))
             except Exception:
                 continue  # unreadable background files are skipped, as in the reference (:119-123)
         return clips
@@ -157,7 +223,7 @@ class AudioProcessor:
     def transform(self, filepath: str, label: int) -> np.ndarray:
         """One file -> MFCC ``[frames, numcep]`` with the reference's augmentation order (``:130-170``)."""
         try:
-            audio = _to_float_mono(load_pcm16(filepath, self.config.sample_rate))
+            audio = load_audio(filepath, self.config.sample_rate, self.resample)  # float32 mono, as librosa.load returns it
             audio = fix_length(audio, self.config.desired_samples)
             if label == SILENCE_INDEX:
                 audio = np.zeros_like(audio)

@@ -1099,3 +1099,41 @@ def test_streaming_full_size_64_and_257_streams(dev, e2e_golden, use_graph):
         assert err <= TOL, (s, err)
         assert_labels_match(y257[s:s + 1], ref, err)
     assert len(np.unique(y257)) >= 3 and float(l257.std(axis=0).mean()) >= 0.1
+
+
+def test_infer_files_of_any_wav_encoding(dev, tmp_path, e2e_golden):
+    """inference(wav) on files that are not 16-bit mono PCM: 24-bit and float32 stereo are decoded to float32 mono as
+    librosa.load does (load_audio) and take the float32 path (kws_infer_f32); the labels are the oracle's for the same
+    float signals.  A 16-bit mono file next to them still gets the label of the int16 path."""
+    import struct
+
+    from kws.inference import KeywordSpotter
+    from kws.libs.audio_processor import load_audio
+
+    model = he_model(e2e_golden)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    sp = KeywordSpotter(model)
+    clips = e2e_golden["clips"]
+
+    def write(path, payload, tag, ch, bits):
+        block = ch * bits // 8
+        fmt = struct.pack("<HHIIHH", tag, ch, 16000, 16000 * block, block, bits)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+    a, b, c = clips[15].astype(np.int32), clips[30].astype(np.int32), clips[40]
+    v24 = (a << 8) + 77                                                      # 24-bit samples that are not 16-bit values
+    write(tmp_path / "x24.wav", b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in v24), 1, 1, 24)
+    st = np.stack([a / 32768.0, b / 32768.0 * 0.5], axis=1).astype("<f4")    # float32 stereo
+    write(tmp_path / "xf32s.wav", st.tobytes(), 3, 2, 32)
+    write(tmp_path / "x16.wav", c.tobytes(), 1, 1, 16)
+    files = [str(tmp_path / n) for n in ("x24.wav", "xf32s.wav", "x16.wav")]
+    got = sp.infer_files(files)
+    sigs = [load_audio(f) for f in files]
+    feats = np.stack([o_mfcc.mfcc(s_, o_mfcc.DEFAULT_SPEC).astype(np.float32) for s_ in sigs])[:, None]
+    want = o_dscnn.forward(state, torch.from_numpy(feats))
+    assert [g[0] for g in got] == o_dscnn.predict(want).tolist()
+    assert got[2][0] == int(e2e_golden["he.label"][8 + 40])                  # the 16-bit file: same label as the int16 path
+    labels, logits = sp.infer_f32(np.stack(sigs))
+    assert np.abs(logits - want.numpy()).max() <= TOL
