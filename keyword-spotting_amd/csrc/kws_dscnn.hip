@@ -569,6 +569,12 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 }
             }
             auto epilogue = [&]() {
+                // relu() is inline asm: the compiler's hazard recognizer does not see that it reads MFMA results, and the
+                // hardware does not interlock a VALU read behind a matrix-core write (XDL write -> VALU read: up to 18 wait
+                // states for a 16-pass MFMA).  The wait is spelled out here; the +v ties pin it after the last MFMA.
+                // (Round 1's `valid ? relu(x) : 0` happened to put an exec-mask branch in between; a branch-free select
+                // read stale accumulators: nondeterministic sums.)
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
                 if constexpr (N < 4) {
                     if (valid) {
 #pragma unroll
@@ -580,10 +586,14 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                         }
                     }
                 } else {
+                    // relu is an asm statement: written as `valid ? relu(x) : 0` every element became its own exec-masked
+                    // branch region (16 per unit).  An AND with an all-ones / all-zeros mask selects without a branch -- and,
+                    // unlike a 0/1 factor, also if a halo lane ever held a NaN.
+                    const uint32_t keep = valid ? 0xffffffffu : 0u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        psum[0][r] += valid ? relu(acc0[r]) : 0.f;
-                        psum[1][r] += valid ? relu(acc1[r]) : 0.f;
+                        psum[0][r] += __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, relu(acc0[r])) & keep);
+                        psum[1][r] += __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, relu(acc1[r])) & keep);
                     }
                     if (act4 && valid) {
 #pragma unroll
@@ -648,14 +658,101 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
         if constexpr (N < 4) {
             if (wv >= G::TILES) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
         } else {
-            // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips)
+            // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips).  Step-major:
+            // all 32 sums take a shift step before any takes the next, so a value is read by DPP well after it was written and
+            // the VALU -> DPP wait states cost no s_nop (register-major the compiler padded every add: 132 s_nop per clip
+            // and wavefront; as builtins it splits every add into v_mov_b32_dpp + v_add_f32).
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
+                float (&q)[16] = psum[ct];
+                // sixteen sums per block, step-major and fused (v_add_f32_dpp reads its own destination shifted): a register is
+                // read by DPP sixteen instructions after it was written, so no wait states are owed
+                asm volatile("s_nop 4\n\t"  // also covers an EXEC write just before the block (5 wait states before DPP)
+                    "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %8, %8, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %9, %9, %9 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %10, %10, %10 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %11, %11, %11 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %12, %12, %12 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %13, %13, %13 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %14, %14, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %15, %15, %15 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %5, %5, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %6, %6, %6 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %7, %7, %7 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %8, %8, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %9, %9, %9 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %10, %10, %10 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %11, %11, %11 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %12, %12, %12 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %13, %13, %13 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %14, %14, %14 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %15, %15, %15 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %5, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %6, %6, %6 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %7, %7, %7 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %8, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %9, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %10, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %11, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %12, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %13, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %14, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %15, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %4, %4, %4 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %5, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %6, %6, %6 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %7, %7, %7 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %8, %8, %8 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %9, %9, %9 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %10, %10, %10 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %11, %11, %11 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %12, %12, %12 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %13, %13, %13 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %14, %14, %14 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %15, %15, %15 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %8, %8, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %9, %9, %9 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %10, %10, %10 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %11, %11, %11 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %12, %12, %12 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %13, %13, %13 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %14, %14, %14 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %15, %15, %15 row_bcast:15 row_mask:0xa bank_mask:0xf"
+                    : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
+            }
+            if (col == 31) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = half_wave_sum_to_last_lane(psum[ct][r]);
-                    if (col == 31) poolbuf[wv * CH + ct * 32 + row_of(r, half)] = s;
-                }
+                for (int k = 0; k < 32; ++k) poolbuf[wv * CH + (k >> 4) * 32 + row_of(k & 15, half)] = psum[k >> 4][k & 15];
             }
         }
     }

@@ -9,13 +9,13 @@ from kws import _native
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
 ctx = _native.Context(0); ctx.use_torch_stream()
-ctx.load_dscnn(bench.synth_weights(), 12)
+ctx.load_dscnn(bench.bench_weights()[0], 12)
 wav = torch.from_numpy(bench.synth_clips(B, 0)).to(dev)
 feat = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
 ctx.mfcc_i16(wav, feat)
 logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
 labels = torch.empty((B,), dtype=torch.int32, device=dev)
-for _ in range(10): ctx.forward_f32(feat, logits, labels)
+for _ in range(100): ctx.forward_f32(feat, logits, labels)  # clocks settle
 torch.cuda.synchronize()
 best = 1e9
 for rep in range(5):
