@@ -58,6 +58,7 @@ CNNTRAD_FLOP_PER_CLIP = CNNTRAD_CONV_FLOP_PER_CLIP + 2 * (19008 * 32 + 32 * 128 
 # executed on the bf16 pipe: conv1 33 tiles x 2 channel tiles x 10 k-blocks, conv2 10 x 2 x 160, six products each
 CNNTRAD_CONV_EXECUTED_BF16_FLOP_PER_CLIP = (33 * 2 * 10 + 10 * 2 * 160) * 6 * 32 * 32 * 16 * 2
 GOLDEN = os.path.join(ROOT, "tests", "golden", "e2e_golden.npz")
+LAUNCH_TIMEOUT_S = 1800                        # self-launched N > 1 runs: the parent gives its children this long
 
 
 # ------------------------------------------------------------------------------------------ host-only helpers
@@ -305,8 +306,15 @@ def launch_children(n: int, argv) -> int:
         env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    try:
+        out0, _ = procs[0].communicate(timeout=LAUNCH_TIMEOUT_S)
+        codes = [procs[0].returncode] + [p.wait(timeout=60) for p in procs[1:]]
+    except subprocess.TimeoutExpired:
+        for p in procs:  # exactly the children this launcher started, nothing matched by name
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"bench.py launcher: ranks still running after {LAUNCH_TIMEOUT_S} s were killed\n")
+        return 124
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]

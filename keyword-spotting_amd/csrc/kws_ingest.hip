@@ -199,13 +199,16 @@ static int ingest_collect(kws_ctx* c, IngestSlot& s, float* h_logits, int32_t* h
     return KWS_OK;
 }
 
-static bool is_pinned_host(const void* p) {
+// 0: ordinary (pageable) host memory, 1: pinned / registered host memory (the DMA can read it), -1: not host memory at all
+static int host_pointer_kind(const void* p) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError();  // an ordinary malloc'ed pointer is "invalid value" for the query: not an error here
-        return false;
+        return 0;
     }
-    return a.type == hipMemoryTypeHost;
+    if (a.type == hipMemoryTypeHost) return 1;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return -1;
+    return 0;  // unregistered / managed: treated as pageable
 }
 
 }  // namespace kws
@@ -245,7 +248,10 @@ int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits,
             for (auto& t : g->slots) t.count = 0;
             break;
         }
-    const bool direct = is_pinned_host(h_wav);  // the DMA can read the caller's buffer: no pack stage
+    const int kind = host_pointer_kind(h_wav);
+    if (kind < 0 || host_pointer_kind(h_logits) < 0 || (h_label && host_pointer_kind(h_label) < 0))
+        return fail(c, KWS_EINVAL, "kws_infer_host_i16: h_wav / h_logits / h_label must be HOST pointers (device tensors go to kws_infer_i16)");
+    const bool direct = kind == 1;  // the DMA can read the caller's buffer: no pack stage
     int next = 0, lane = 0;
     for (int first = 0; first < B; first += g->chunk, next = (next + 1) % g->n_slots, lane ^= 1) {
         IngestSlot& s = g->slots[next];

@@ -270,6 +270,9 @@ __device__ __forceinline__ PairLevel equalise_levels(cf (&v)[8]) {
         return s < -30 ? -30 : (s > 30 ? 30 : s);                                  // 2^(+-60) on the powers stays far from the f32 limits
     };
     const int sa = shift_of(ea), sb = shift_of(eb);
+    // Equal exponents (stationary signals: most pairs): scaling both frames by the same power of two commutes with every
+    // rounding of the transform, so the unscaled transform gives the same bits -- skip the multiplies (wave-uniform branch).
+    if (sa == sb) return {1.0f, 1.0f};
     const cf down = {__builtin_bit_cast(float, (uint32_t)(127 - sa) << 23), __builtin_bit_cast(float, (uint32_t)(127 - sb) << 23)};
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = v[i] * down;

@@ -819,6 +819,12 @@ def test_host_ingest_pipeline(native, dev, e2e_golden):
         assert np.array_equal(logits, want_logits)
         with pytest.raises(ModelError):
             c.ingest_config(0, 1, 0)                                # fewer than two slots cannot overlap anything
+        import ctypes
+        d_wav = torch.from_numpy(big[:8]).to(dev)                   # a DEVICE pointer where a host pointer belongs: refused, not dereferenced
+        out_l, out_y = np.empty((8, 12), np.float32), np.empty((8,), np.int32)
+        rc = native.lib().kws_infer_host_i16(c._h, ctypes.c_void_p(d_wav.data_ptr()), 8, ctypes.c_void_p(out_l.ctypes.data),
+                                             ctypes.c_void_p(out_y.ctypes.data))
+        assert rc == native.KWS_EINVAL
     finally:
         c.close()
     sp = KeywordSpotter(model)
