@@ -84,7 +84,7 @@ bool build_mel_host(int nfilt, int nfft, int sample_rate, MelHost& out, std::str
         int c = seg_first[s];
         for (int k0 = lo; k0 < hi; k0 += MEL_CHUNK, ++c) {
             out.k0[c] = k0;
-            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) out.slot[k0 + i] = MEL_CHUNK * c + i;
+            for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) out.slot[k0 + i] = MEL_STRIDE * c + i;
             for (int i = 0; i < MEL_CHUNK && k0 + i < hi; ++i) {
                 const double k = k0 + i, width = (double)(hi - lo);
                 if (s < nfilt) out.rw[i * 64 + c] = (float)((k - lo) / width);

@@ -16,6 +16,9 @@ namespace kws {
 constexpr int NFFT = 512;
 constexpr int NBINS = NFFT / 2 + 1;       // 257
 constexpr int MEL_CHUNK = 8;              // bins per lane in the sparse mel stage
+constexpr int MEL_STRIDE = 10;            // power-buffer slots (float2) from one lane's chunk to the next: 80 bytes, so the sixteen
+                                          // lanes of a ds_read_b128 group start on sixteen different 16-byte bank groups (with 64
+                                          // bytes every fourth lane collided: 48 of the mel stage's LDS cycles per frame pair)
 #ifndef KWS_MFCC_WAVES
 #define KWS_MFCC_WAVES 4
 #endif
@@ -50,7 +53,7 @@ struct FrontendTables {
     const float* mel_rw;       // [8][64]    rising-edge weights of the chunk's bins (0 beyond its length)
     const float* mel_fw;       // [8][64]    falling-edge weights
     const uint32_t* mel_gather;// [64]       per filter: r0 | nr<<8 | f0<<16 | nf<<24  (chunk ranges)
-    const int* mel_slot;       // [256]      power-buffer slot of bin k = 8*chunk(k) + (k - first bin of the chunk)
+    const int* mel_slot;       // [256]      power-buffer slot of bin k = MEL_STRIDE*chunk(k) + (k - first bin of the chunk)
     const int* mel_seg;        // [64]       per chunk: bit d (0..2) = chunk + 2^d is in the same segment; bit 6 = no segment straddles a 16-lane row; bit 7 = deep
     const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
     // float64 kernel (kws_mfcc_f64.hip)

@@ -92,6 +92,7 @@ constexpr int XROW = 72;
 
 // Per-wavefront LDS scratch (bytes): exchange / spectrum / power buffer, log-mel vectors.
 constexpr int SCR_XBUF = 0, SCR_PBUF = 0, SCR_LBUF = 4608, SCR_BYTES = 4608 + 512;
+static_assert(64 * MEL_STRIDE * 8 <= SCR_BYTES, "the power buffer (64 chunks of MEL_STRIDE float2) may run over the log-mel vectors, which are written after its last read, but not out of the wavefront's scratch");
 static_assert(KWS_MFCC_WAVES * SCR_BYTES >= NFFT * 4, "frame loads may run up to NFFT floats past the staged span, into the scratch");
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
@@ -460,17 +461,27 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     const uint32_t gth = ml.gth;
     const int nfp = sc.nfp;
     const PairLevel lv = equalise_levels(v);
+#if !defined(KWS_X_MFCC_STOP) || KWS_X_MFCC_STOP >= 1
     fft512(v, xbuf, t1, tw2, lane);
+#endif
+#if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP <= 1   // counter attribution (tools/pmc_mfcc_variant.sh): stop after the transform; wrong results
+    if (lane < p.numcep) out_a[lane] = v[0].x + v[1].y + v[2].x + v[3].y + v[4].x + v[5].y + v[6].x + v[7].y + lv.pow_a;
+    return;
+#endif
 
     float ea, eb;
     split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb);
     wave_sum2(ea, eb);
+#if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 2    // stop after the power spectrum
+    if (lane < p.numcep) out_a[lane] = ea + eb + pbuf[lane].x;
+    return;
+#endif
 
     // sparse mel: this lane's chunk of <= 8 bins is one contiguous 64-byte run of the power buffer (four
     // conflict-free ds_read_b128); slots past the chunk's length hold stale finite values and meet zero weights
     float ra = 0.f, fa_ = 0.f, rb = 0.f, fb_ = 0.f;
     {
-        const float4* pc = reinterpret_cast<const float4*>(pbuf + lane * MEL_CHUNK);
+        const float4* pc = reinterpret_cast<const float4*>(pbuf + lane * MEL_STRIDE);
 #pragma unroll
         for (int h = 0; h < MEL_CHUNK / 2; ++h) {
             const float4 pw = pc[h];  // (bin 2h: frame a, frame b), (bin 2h+1: frame a, frame b)
@@ -502,6 +513,10 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
             lb = logf(sb == 0.f ? PSF_EPS : sb);
         }
     }
+#if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 3    // stop after mel + log
+    if (lane < p.numcep) out_a[lane] = la + lb + ea + eb;
+    return;
+#endif
     // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
     // table-rounding error a -36 log-floor would otherwise amplify.
     const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
