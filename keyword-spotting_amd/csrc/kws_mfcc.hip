@@ -499,30 +499,39 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     // lanes: a suffix sum by doubling (DPP shifts, no LDS) leaves each segment's total in its first chunk, and lane
     // j fetches its two totals through the LDS crossbar (ds_bpermute: no memory, no bank conflicts).
     segment_suffix_sums(ra, fa_, rb, fb_, ml);
-    float la = 0.f, lb = 0.f;
+    float ma, mb;
     {
         const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
         const float gra = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * r0, __builtin_bit_cast(int, ra)));
         const float grb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * r0, __builtin_bit_cast(int, rb)));
         const float gfa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * q0, __builtin_bit_cast(int, fa_)));
         const float gfb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * q0, __builtin_bit_cast(int, fb_)));
-        if (lane < p.nfilt) {
-            const float sa = (nr ? gra : 0.f) + (nq ? gfa : 0.f);
-            const float sb = (nr ? grb : 0.f) + (nq ? gfb : 0.f);
-            la = logf(sa == 0.f ? PSF_EPS : sa);
-            lb = logf(sb == 0.f ? PSF_EPS : sb);
+        const float sa = (nr ? gra : 0.f) + (nq ? gfa : 0.f);
+        const float sb = (nr ? grb : 0.f) + (nq ? gfb : 0.f);
+        if (p.nfilt <= 32) {
+            // both frames through ONE log: frame b's filterbank energies move to lanes 32.. (v_permlane32_swap
+            // exchanges the upper half of its first operand with the lower half of its second)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sa), __builtin_bit_cast(unsigned, sb), false, false);
+            const float s = __builtin_bit_cast(float, (unsigned)sw[0]);
+            const float l = logf(s == 0.f ? PSF_EPS : s);
+            // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
+            // table-rounding error a -36 log-floor would otherwise amplify.
+            ma = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), 0));
+            mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), 32));
+#if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 3    // stop after mel + log
+            if (lane < p.numcep) out_a[lane] = l + ea + eb;
+            return;
+#endif
+            const int f = lane >> 5, j = lane & 31;
+            lbuf[64 * f + j] = j < p.nfilt ? l - (f ? mb : ma) : 0.f;
+        } else {
+            const float la = logf(sa == 0.f ? PSF_EPS : sa), lb = logf(sb == 0.f ? PSF_EPS : sb);
+            ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
+            mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
+            lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
+            lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
         }
     }
-#if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 3    // stop after mel + log
-    if (lane < p.numcep) out_a[lane] = la + lb + ea + eb;
-    return;
-#endif
-    // DCT rows k >= 1 are orthogonal to constants: removing the common mode L_0 removes the float32
-    // table-rounding error a -36 log-floor would otherwise amplify.
-    const float ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
-    const float mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
-    lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
-    lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
     wave_lds_order();
 
     // DCT-II(ortho) x lifter: lane -> (frame f = lane>>5, coefficient i = lane&31)
@@ -577,7 +586,9 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// TAIL6: frame_len in (384, 448] (the reference's 400): sample blocks n1 < 6 lie wholly inside the frame, block 6 is cut
+// by a lane bound and block 7 is zero -- no loads or selects for it, and the zeros fold through the first butterflies.
+template <typename T, bool TAIL6>
 __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const FrontendTables& t, const T* __restrict__ wav,
                                           float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -662,15 +673,36 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         // patterns (sign bit dropped: -0.0 counts as zero, like the float comparison).
         cf v[8];
         uint32_t ora = 0u, orb = 0u;
+        if constexpr (TAIL6) {
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) {
-            const int i = 64 * n1 + lane;
-            const bool in = i < p.frame_len;
-            const float la = ya[i], lb = yb[i];  // loaded whether or not they are used (see above)
-            const float a = in ? la : 0.f, b = (in && has_b) ? lb : 0.f;
-            v[n1] = cf{a, b};
-            ora |= __builtin_bit_cast(uint32_t, a);  // (bit_cast of a vector ELEMENT reads element 0 with this clang:
-            orb |= __builtin_bit_cast(uint32_t, b);  //  cast the scalars)
+            for (int n1 = 0; n1 < 7; ++n1) {
+                const int i = 64 * n1 + lane;
+                float a = ya[i], b = yb[i];
+                if (n1 == 6) {
+                    const bool in = i < p.frame_len;
+                    a = in ? a : 0.f, b = in ? b : 0.f;
+                }
+                v[n1] = cf{a, b};
+                ora |= __builtin_bit_cast(uint32_t, a);
+                orb |= __builtin_bit_cast(uint32_t, b);
+            }
+            v[7] = cf{0.f, 0.f};
+            if (!has_b) {  // wave-uniform, the clip's last pair only: frame b is past the clip
+#pragma unroll
+                for (int n1 = 0; n1 < 7; ++n1) v[n1].y = 0.f;
+                orb = 0u;
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int i = 64 * n1 + lane;
+                const bool in = i < p.frame_len;
+                const float la = ya[i], lb = yb[i];  // loaded whether or not they are used (see above)
+                const float a = in ? la : 0.f, b = (in && has_b) ? lb : 0.f;
+                v[n1] = cf{a, b};
+                ora |= __builtin_bit_cast(uint32_t, a);  // (bit_cast of a vector ELEMENT reads element 0 with this clang:
+                orb |= __builtin_bit_cast(uint32_t, b);  //  cast the scalars)
+            }
         }
         const bool nza = __any((ora << 1) != 0u);
         const bool nzb = __any((orb << 1) != 0u);
@@ -686,15 +718,27 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
 #endif
 // amdgpu_waves_per_eu(4, 4): 128 registers, so that the four 4-wave workgroups the LDS admits per CU (16
 // wavefronts, 4 per SIMD) all become resident; the kernel is latency-bound on LDS round trips.
+// kws_mfcc_{i16,f32}_kernel: frame lengths in (384, 448] (the reference's 400 samples), see TAIL6; the *_any_kernel pair
+// takes every other frame length up to 512 (one kernel with both bodies spills registers).
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
                                                                     float* __restrict__ out) {
-    mfcc_body<int16_t>(p, t, wav, out);
+    mfcc_body<int16_t, true>(p, t, wav, out);
 }
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
                                                                     const float* __restrict__ wav,
                                                                     float* __restrict__ out) {
-    mfcc_body<float>(p, t, wav, out);
+    mfcc_body<float, true>(p, t, wav, out);
+}
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_any_kernel(FrontendParams p, FrontendTables t,
+                                                                    const int16_t* __restrict__ wav,
+                                                                    float* __restrict__ out) {
+    mfcc_body<int16_t, false>(p, t, wav, out);
+}
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_f32_any_kernel(FrontendParams p, FrontendTables t,
+                                                                    const float* __restrict__ wav,
+                                                                    float* __restrict__ out) {
+    mfcc_body<float, false>(p, t, wav, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -905,11 +949,13 @@ static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p
 
 hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B,
                        float* d_out) {
-    return launch_mfcc_t(kws_mfcc_i16_kernel, s, p, t, d_wav, B, d_out);
+    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
+    return launch_mfcc_t(tail6 ? kws_mfcc_i16_kernel : kws_mfcc_i16_any_kernel, s, p, t, d_wav, B, d_out);
 }
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
                            float* d_out) {
-    return launch_mfcc_t(kws_mfcc_f32_kernel, s, p, t, d_wav, B, d_out);
+    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
+    return launch_mfcc_t(tail6 ? kws_mfcc_f32_kernel : kws_mfcc_f32_any_kernel, s, p, t, d_wav, B, d_out);
 }
 
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
