@@ -52,6 +52,9 @@ namespace {
 #ifndef KWS_DSCNN_WAVES
 #define KWS_DSCNN_WAVES 8
 #endif
+#ifndef KWS_X_DSCNN_STAMP_TID   // diagnostics builds (tools/build_variant.sh): which thread writes the phase stamps
+#define KWS_X_DSCNN_STAMP_TID 0
+#endif
 constexpr int NW = KWS_DSCNN_WAVES;  // wavefronts per workgroup (8 = 2 per SIMD; 12 = 3 per SIMD measured slower)
 constexpr int NT = NW * 64;
 constexpr int TW = 30;               // output positions per tile (32 MFMA columns - 2 halo columns)
@@ -785,10 +788,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     // phase boundaries, KWS_DSCNN_STAMPS per clip; [14] and [15] carry the 100 MHz real-time counter
     int n_stamp = 0;
     auto stamp = [&]() {
-        if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + n_stamp] = __builtin_amdgcn_s_memtime();
+        if (stamps && tid == KWS_X_DSCNN_STAMP_TID) stamps[(size_t)clip * KWS_DSCNN_STAMPS + n_stamp] = __builtin_amdgcn_s_memtime();
         ++n_stamp;
     };
-    if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 2] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && tid == KWS_X_DSCNN_STAMP_TID) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 2] = __builtin_amdgcn_s_memrealtime();
     stamp();  // 0: start
 
     constexpr bool SPLIT = MODE >= 4;
@@ -957,7 +960,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         if (label && lane == 0) label[clip] = idx;
     }
     stamp();  // 12: pool + fc + argmax done
-    if (stamps && tid == 0) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 1] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && tid == KWS_X_DSCNN_STAMP_TID) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace
