@@ -324,6 +324,11 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
             melw[(size_t)nb64 + i] = (double)(edges[j + 1] - i) / width;
         }
 
+    const int nfp = (nfilt + 3) & ~3;
+    std::vector<float> dct_pad(((size_t)numcep * nfp + 3) & ~(size_t)3, 0.f);
+    for (int i = 0; i < numcep; ++i)
+        for (int j = 0; j < nfilt; ++j) dct_pad[(size_t)i * nfp + j] = dct[(size_t)i * nfilt + j];
+
     // one device allocation, every table 256-byte aligned
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_tw = 0, o_k0 = al(o_tw + sizeof(float2) * NFFT), o_rw = al(o_k0 + sizeof(int) * 64),
@@ -331,7 +336,8 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
                  o_dct = al(o_g + sizeof(uint32_t) * 64), o_slot = al(o_dct + sizeof(float) * dct.size()),
                  o_seg = al(o_slot + sizeof(int) * (NFFT / 2)), o_tw64 = al(o_seg + sizeof(int) * 64),
                  o_edges = al(o_tw64 + sizeof(double) * tw64.size()), o_dct64 = al(o_edges + sizeof(int) * edges.size()),
-                 o_melw = al(o_dct64 + sizeof(double) * dct64.size()), total = al(o_melw + sizeof(double) * melw.size());
+                 o_melw = al(o_dct64 + sizeof(double) * dct64.size()), o_dctp = al(o_melw + sizeof(double) * melw.size()),
+                 total = al(o_dctp + sizeof(float) * dct_pad.size());
     std::vector<unsigned char> host(total, 0);
     memcpy(&host[o_tw], tw.data(), sizeof(float2) * NFFT);
     memcpy(&host[o_k0], mel.k0.data(), sizeof(int) * 64);
@@ -345,6 +351,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     memcpy(&host[o_edges], edges.data(), sizeof(int) * edges.size());
     memcpy(&host[o_dct64], dct64.data(), sizeof(double) * dct64.size());
     memcpy(&host[o_melw], melw.data(), sizeof(double) * melw.size());
+    memcpy(&host[o_dctp], dct_pad.data(), sizeof(float) * dct_pad.size());
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // tables of the previous configuration may be in use
@@ -371,6 +378,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->ft.mel_edges = reinterpret_cast<const int*>(b + o_edges);
     c->ft.dct64 = reinterpret_cast<const double*>(b + o_dct64);
     c->ft.mel_w64 = reinterpret_cast<const double*>(b + o_melw);
+    c->ft.dct_pad = reinterpret_cast<const float*>(b + o_dctp);
 
     FrontendParams& p = c->fp;
     p.n_samples = n_samples;

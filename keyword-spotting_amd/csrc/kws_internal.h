@@ -56,6 +56,7 @@ struct FrontendTables {
     const int* mel_slot;       // [256]      power-buffer slot of bin k = MEL_STRIDE*chunk(k) + (k - first bin of the chunk)
     const int* mel_seg;        // [64]       per chunk: bit d (0..2) = chunk + 2^d is in the same segment; bit 6 = no segment straddles a 16-lane row; bit 7 = deep
     const float* dct;          // [numcep][nfilt]  DCT-II ortho x lifter
+    const float* dct_pad;      // [numcep][nfp]    the same, rows zero-padded to nfp = (nfilt+3)&~3 floats (the LDS image, copied as float4)
     // float64 kernel (kws_mfcc_f64.hip)
     const double* tw64;        // [nfft][2]  (cos, -sin)(2*pi*k/nfft)
     const int* mel_edges;      // [nfilt+2]  psf's bin edges
