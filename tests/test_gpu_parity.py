@@ -175,6 +175,27 @@ def test_mfcc_other_geometry(native, dev):
         c.close()
 
 
+@pytest.mark.parametrize("frame_len", [320, 384, 385, 400, 447, 448, 449, 512])
+def test_mfcc_frame_length_boundaries(native, dev, frame_len):
+    """The float32 kernel has two instantiations: frame lengths in (384, 448] (the reference's 400: the eighth 64-sample
+    block of a frame is empty, the seventh is cut by a lane bound) and every other length up to 512.  Both sides of each
+    boundary, odd frame counts (the last pair has no partner) and a batch that is not a multiple of anything."""
+    c = make_ctx(native)
+    try:
+        n = 16000 // 2 + 37
+        spec = o_mfcc.FrontendSpec(sample_rate=16000, n_samples=n, winlen=frame_len / 16000.0, winstep=0.01, nfft=512)
+        assert spec.frame_len == frame_len
+        c.set_frontend(sample_rate=16000, n_samples=n, frame_len=frame_len, frame_step=160, nfft=512)
+        clips = np.random.default_rng(frame_len).integers(-20000, 20000, size=(5, n), dtype=np.int16)
+        clips[3, : n // 2] = 0  # leading silence: all-zero frames beside live ones
+        got = gpu_mfcc(c, dev, clips)[:, 0]
+        want = np.stack([o_mfcc.mfcc(o_mfcc.pcm16_to_float(x), spec) for x in clips])
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= TOL
+    finally:
+        c.close()
+
+
 def test_frontend_rejects_unsupported(native):
     from kws.common.errors import AudioProcessingError
 
