@@ -11,7 +11,7 @@ mkdir -p "$OBJ"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wall -Wno-unused-function -fvisibility=hidden -ffp-contract=off -DKWS_BUILD $*"
 for f in kws_api kws_ingest kws_dsblock kws_mfcc kws_mfcc_f64 kws_dscnn kws_cnntrad; do
   # only the translation units a macro can touch are rebuilt per variant; the others are linked from the main build
-  if [ "$f" != kws_api ] && [ -f "$SRC/build/$f.o" ] && ! grep -q "KWS_MFCC_\|KWS_DSCNN_\|KWS_X_" "$SRC/$f.hip"; then cp "$SRC/build/$f.o" "$OBJ/$f.o"; continue; fi
+  if [ "$f" != kws_api ] && [ -f "$SRC/build/$f.o" ] && ! grep -q "KWS_MFCC_\|KWS_DSCNN_\|KWS_X_\|kws_mfcc_dev.h" "$SRC/$f.hip"; then cp "$SRC/build/$f.o" "$OBJ/$f.o"; continue; fi
   /opt/rocm/bin/hipcc $FLAGS -c "$SRC/$f.hip" -o "$OBJ/$f.o" &
 done
 wait
