@@ -547,8 +547,11 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
             k_ms, k_n = ctx.prof_read(_native.KWS_K_DSCNN)
             f_ms, f_n = ctx.prof_read(_native.KWS_K_STREAM_FRAME)
             ctx.prof_enable(False)
-            res[mode]["kernel_us"] = {_native.kernel_name(_native.KWS_K_DSCNN): k_ms / max(k_n, 1) * 1e3,
-                                      _native.kernel_name(_native.KWS_K_STREAM_FRAME): f_ms / max(f_n, 1) * 1e3}
+            # one launch per push: the one-frame front end runs in the prologue of the DS-CNN kernel (f_n == 0)
+            res[mode]["kernel_us"] = {_native.kernel_name(_native.KWS_K_DSCNN): k_ms / max(k_n, 1) * 1e3}
+            if f_n:
+                res[mode]["kernel_us"][_native.kernel_name(_native.KWS_K_STREAM_FRAME)] = f_ms / f_n * 1e3
+            res[mode]["launches_per_push"] = 2 if f_n else 1
             dscnn_ms, dscnn_n = k_ms / max(k_n, 1), k_n
             final_logits = logits.cpu().numpy()
         else:
@@ -561,8 +564,8 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
            "value": res[best]["p50_us"], "unit": "us p50 per hop", "higher_is_better": False, "p99_us": res[best]["p99_us"], "mode": best,
            "eager": res["eager"], "hipgraph": res["hipgraph"], "real_time_factor_p50": 10000.0 / res[best]["p50_us"], "dtype": "f32",
            "roofline": dscnn_roofline(_native, dscnn_n, dscnn_ms, S, "stream"),
-           "note": f"latency-bound: {S} workgroups on 256 CUs, a clip's critical path through the DS-CNN kernel is ~30 us; the roofline "
-                   "fraction is reported for completeness"}
+           "note": f"latency-bound: {S} workgroups on 256 CUs, one launch per push (each stream's new MFCC frame is computed in the prologue "
+                   "of its DS-CNN workgroup); a clip's critical path through the kernel is ~33 us; the roofline fraction is reported for completeness"}
     if cpu_check:
         import torch as _t
 

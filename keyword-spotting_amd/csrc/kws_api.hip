@@ -991,9 +991,20 @@ int kws_stream_close(kws_ctx* c) {
     return KWS_OK;
 }
 
-// timed: bracket the two launches with profiling events (eager pushes only; never inside a stream capture)
+// timed: bracket the launches with profiling events (eager pushes only; never inside a stream capture).
+// A push that asks for logits from the product DS-CNN is ONE launch: each stream's workgroup computes the stream's new
+// frame in its prologue (launch_dscnn_stream).  Features-only pushes, and the diagnostic pointwise variants, take the
+// frame kernel followed -- if logits are wanted -- by the DS-CNN kernel over the advanced ring.
 static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label, bool timed) {
     hipError_t e;
+    if (d_logits && c->pw_math == KWS_PW_SPLIT_BF16) {
+        const bool was = c->prof;
+        c->prof = was && timed;
+        ProfScope ps(c, KWS_K_DSCNN);
+        c->prof = was;
+        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops};
+        return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label);
+    }
     {
         const bool was = c->prof;
         c->prof = was && timed;

@@ -43,6 +43,7 @@
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
 //   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled
 #include "kws_internal.h"
+#include "kws_mfcc_dev.h"
 #include "kws_split_mfma.h"
 
 namespace kws {
@@ -123,11 +124,7 @@ __device__ __forceinline__ float stencil3x3(float w0, float w1, float w2, float 
 }
 // Sum over each 32-lane half of the wavefront without touching LDS: inclusive scan inside the 16-lane rows
 // (row_shr 1,2,4,8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15).  Lanes 31 and 63 hold the totals.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_shift_add(float v) {
-    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
-    return v + o;
-}
+// (dpp_shift_add<CTRL, ROW_MASK>: kws_mfcc_dev.h)
 __device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
     v = dpp_shift_add<0x111, 0xf>(v);  // row_shr:1
     v = dpp_shift_add<0x112, 0xf>(v);  // row_shr:2
@@ -767,12 +764,16 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 // registers and 5 KB of code even when unused).
 // PRECONV: `feat` is not the MFCC map but conv1's output [B][64][47*3] (ReLU applied), computed by kws_conv1_general_kernel
 // for a model with input_channels > 1 (models.py:125,135); the kernel then starts at block 1.
-template <int MODE, bool DIAG = true, bool PRECONV = false>
+// STREAM: the streaming push in one launch (launch_dscnn_stream).  `feat` is the feature ring (its newest row is written
+// here, through a pointer derived from `feat`, and never read), wavefront 0 computes the stream's new frame straight into the LDS feature map while the other
+// wavefronts fetch the 98 older rows, and the hop counter sp.hops advances when the last workgroup is done.
+template <int MODE, bool DIAG = true, bool PRECONV = false, bool STREAM = false>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
                                                            float* __restrict__ act_arg,
                                                            unsigned long long* __restrict__ stamps_arg,
-                                                           const int* __restrict__ ring_hops) {
+                                                           const int* __restrict__ ring_hops, StreamPush sp) {
+    static_assert(!STREAM || (MODE >= 4 && !DIAG && !PRECONV), "the fused push exists for the product path only");
     float* const act = DIAG ? act_arg : nullptr;
     unsigned long long* const stamps = DIAG ? stamps_arg : nullptr;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -796,6 +797,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     constexpr bool SPLIT = MODE >= 4;
     PwOperands<MODE> wa;            // pointwise operands of the running block
+    int hops_before = 0;            // STREAM: pushes before this one
     if constexpr (PRECONV) {
         static_assert(!PRECONV || MODE >= 4, "the pre-convolved entry exists for the product (split) path only");
         const float* z = feat + (size_t)clip * (CH * P0);
@@ -819,11 +821,21 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     float fv[FV];
     // streaming: the feature map is a ring of IN_T frames; after `hops` pushes the newest frame sits in row
     // (hops - 3) mod IN_T and the window starts one row after it
-    const int head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
+    int row_new = -1;  // STREAM: window row the new frame takes (-1: none yet)
+    int head;
+    if constexpr (STREAM) {
+        hops_before = *sp.hops;
+        head = (((hops_before - 1) % IN_T) + IN_T) % IN_T;  // what the two-launch path derives from the advanced counter
+        const int step = sp.p.frame_step;
+        const long f_start = (long)step * hops_before + step - (long)((sp.p.frame_len + step - 1) / step) * step;
+        if (f_start >= 0) row_new = (int)((((f_start / step) - head) % IN_T + IN_T) % IN_T);
+    } else {
+        head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
+    }
 #pragma unroll
     for (int k = 0; k < FV; ++k) {
         const int i = tid + k * NT;
-        fv[k] = i < IN_T * IN_F ? f[((i / IN_F + head) % IN_T) * IN_F + i % IN_F] : 0.f;
+        fv[k] = (i < IN_T * IN_F && i / IN_F != row_new) ? f[((i / IN_F + head) % IN_T) * IN_F + i % IN_F] : 0.f;
     }
     BlockTables t1;
     fetch_block_tables(w, 1, tid, t1);
@@ -843,6 +855,26 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         load_pointwise(w, 1, lane, wa);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STREAM) {
+        // One barrier: the zero fill touches only the padding, the scatter only the interior, and the new frame's row is
+        // written by wavefront 0 alone, straight from the cepstrum registers of its one-frame front end (scratch and tables
+        // in the region block 2 will overwrite much later).
+        if (wv == 0)  // first: its sample and table loads join the feature loads already in flight
+            stream_frame_wave(sp.p, sp.t, sp.hop, clip, clip, false, sp.pcm_ring, sp.ring_len, const_cast<float*>(feat), hops_before,
+                              reinterpret_cast<unsigned char*>(lds + OFF_Z2), lane,
+                              row_new >= 0 ? featp + (row_new + 2) * FEAT_W + 2 : nullptr);
+        for (int i = tid; i < FEAT_H * FEAT_W; i += NT) {
+            const int r = i / FEAT_W - 2, c = i % FEAT_W - 2;
+            if (!((unsigned)r < (unsigned)IN_T && (unsigned)c < (unsigned)IN_F)) featp[i] = 0.f;
+        }
+        store_block_tables(lds, 1, tid, t1);
+#pragma unroll
+        for (int k = 0; k < FV; ++k) {
+            const int i = tid + k * NT;
+            if (i < IN_T * IN_F && i / IN_F != row_new) featp[(i / IN_F + 2) * FEAT_W + (i % IN_F) + 2] = fv[k];
+        }
+        __syncthreads();
+    } else {
     for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
     store_block_tables(lds, 1, tid, t1);
     __syncthreads();
@@ -852,6 +884,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         if (i < IN_T * IN_F) featp[(i / IN_F + 2) * FEAT_W + (i % IN_F) + 2] = fv[k];
     }
     __syncthreads();
+    }
     stamp();  // 1: features staged
 
     if constexpr (SPLIT) {
@@ -959,6 +992,14 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const int idx = holders ? __ffsll(holders) - 1 : 0;  // all-NaN logits: label 0
         if (label && lane == 0) label[clip] = idx;
     }
+    if constexpr (STREAM) {
+        // hop counter: every workgroup read sp.hops[0] in its prologue; the one that finishes last advances it
+        // (sp.hops[1] counts finished workgroups).  The kernel boundary publishes it to the next push.
+        if (tid == 0 && atomicAdd(&sp.hops[1], 1) == (int)gridDim.x - 1) {
+            sp.hops[1] = 0;
+            sp.hops[0] = hops_before + 1;
+        }
+    }
     stamp();  // 12: pool + fc + argmax done
     if (stamps && tid == KWS_X_DSCNN_STAMP_TID) stamps[(size_t)clip * KWS_DSCNN_STAMPS + KWS_DSCNN_STAMPS - 1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -972,7 +1013,8 @@ hipError_t dscnn_init_device() {
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<2>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<3>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, true>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, true>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -1027,29 +1069,37 @@ hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in
     return hipGetLastError();
 }
 
+hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
+                               float* d_logits, int32_t* d_label) {
+    static_assert(sizeof(float) * (size_t)(LDS_FLOATS - OFF_Z2) >= 16 * 1024, "room for the one-frame front end's tables and scratch");
+    hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true>), dim3(n_streams), dim3(NT), LDS_FLOATS * sizeof(float), s, w,
+                       d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+    return hipGetLastError();
+}
+
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps, const int* d_ring_hops,
                         bool preconv) {
     const size_t lds = LDS_FLOATS * sizeof(float);
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
     if (preconv) {  // d_feat = conv1 output of a multi-channel model (kws_conv1_general_kernel): product path only
-        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr, StreamPush{});
         return hipGetLastError();
     }
     // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /
     // stencil only; wrong results by construction, reachable only through the diagnostics entry point)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
-        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
-        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
+        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
+        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
         case 4:
             if (d_act || d_stamps)
-                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops);
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{});
             else
-                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops);
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{});
             break;
-        case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
-        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops); break;
+        case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
+        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
     }
     return hipGetLastError();
 }

@@ -128,6 +128,19 @@ struct DscnnWeights {
 };
 
 hipError_t dscnn_init_device();
+// The streaming push as ONE launch: every stream's workgroup of the DS-CNN kernel computes that stream's new MFCC frame in
+// its prologue (kws_mfcc_dev.h: stream_frame_wave), appends the hop to the PCM ring, and the last workgroup to finish
+// advances the hop counter.  d_feat_ring: [n_streams][num_frames][numcep]; d_hops: {pushes so far, finished workgroups}.
+struct StreamPush {
+    FrontendParams p;
+    FrontendTables t;
+    const int16_t* hop;      // [n_streams][frame_step]
+    int16_t* pcm_ring;       // [n_streams][ring_len]
+    int ring_len;
+    int* hops;
+};
+hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
+                               float* d_logits, int32_t* d_label);
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
                         const int* d_ring_hops = nullptr, bool preconv = false);

@@ -434,7 +434,8 @@ __device__ __forceinline__ void segment_suffix_sums(float& a, float& b, float& c
 // out_a / out_b: rows of numcep floats for frame a / b (out_b is not touched when has_b is false).
 __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
                                           const PairScratch& sc, const cf (&t1)[8], const MelLane& ml, int lane,
-                                          float* __restrict__ out_a, float* __restrict__ out_b) {
+                                          float* __restrict__ out_a, float* __restrict__ out_b,
+                                          float* lds_out_a = nullptr) {
     cf* xbuf = sc.xbuf;
     float2* pbuf = sc.pbuf;
     float* lbuf = sc.lbuf;
@@ -562,9 +563,130 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
                 }
             }
             (f ? out_b : out_a)[i] = acc;
+            if (lds_out_a && f == 0) lds_out_a[i] = acc;  // the streaming push inside the DS-CNN kernel: the row goes straight to the feature map
         }
     }
     wave_lds_order();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Streaming front end (BASELINE config 5: 10 ms hops), the work of ONE wavefront: every push brings frame_step new
+// samples per stream and completes exactly one new frame per stream.  The wavefront serves stream sa and, when has_b,
+// stream sb (their frames are the two halves of one packed FFT).  hops = pushes seen BEFORE this one; the new frame is
+// frame hops - 2 of the continuous signal and covers samples [step*(hops-2), step*(hops-2) + frame_len).  Samples of
+// the current hop are taken from `hop`, older ones from the per-stream PCM ring, which is also updated here.  The
+// cepstra go to row (frame index mod num_frames) of each stream's feature ring and, when lds_out_a is not null, stream
+// sa's also to those numcep floats in LDS.  smem: stream_frame_lds_bytes(p) bytes of LDS, private to the wavefront.
+// Returns the frame's index in the continuous signal, or -1 while the stream is younger than one frame.
+__device__ __forceinline__ size_t stream_frame_lds_bytes(const FrontendParams& p) {
+    const int nfp = (p.nfilt + 3) & ~3;
+    return sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES;
+}
+__device__ __forceinline__ long stream_frame_wave(const FrontendParams& p, const FrontendTables& t,
+                                                  const int16_t* __restrict__ hop, int sa, int sb, bool has_b,
+                                                  int16_t* __restrict__ pcm_ring, int ring_len,
+                                                  float* __restrict__ feat_ring, int hops, unsigned char* smem, int lane,
+                                                  float* lds_out_a) {
+    const int nfp = (p.nfilt + 3) & ~3;
+    float* dctb = reinterpret_cast<float*>(smem);
+    cf* tw2 = reinterpret_cast<cf*>(dctb + ((p.numcep * nfp + 3) & ~3));
+    unsigned char* scr = reinterpret_cast<unsigned char*>(tw2 + 64);
+    const int step = p.frame_step;
+    const long base = (long)step * hops;            // absolute index of the first sample of this hop
+
+    {   // both float4 of a lane in flight together (13 x 28 floats = 91 float4 at the reference's geometry)
+        const int n4 = (p.numcep * nfp + 3) / 4;
+        const float4* src = reinterpret_cast<const float4*>(t.dct_pad);
+        for (int i0 = 0; i0 < n4; i0 += 128) {
+            const int i = i0 + lane, j = i + 64;
+            const float4 a = i < n4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = j < n4 ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n4) reinterpret_cast<float4*>(dctb)[i] = a;
+            if (j < n4) reinterpret_cast<float4*>(dctb)[j] = b;
+        }
+    }
+    fill_tw2(t.twiddle, tw2, lane);
+    zero_scratch(scr, lane);
+    cf t1[8];
+    load_twiddles(t.twiddle, lane, t1);
+    MelLane ml;
+    load_mel_lane(t, lane, ml);
+
+    // Sample at offset d from the start of this hop (d < step; absolute index base + d) of stream s: d >= 0 -> d_hop,
+    // d < 0 -> the per-stream ring, before the stream began -> 0.  All index arithmetic is 32-bit relative to the hop
+    // (a 64-bit modulo per sample was most of this kernel's time), one load per sample through a selected pointer, and
+    // the previous sample of the pre-emphasis comes from the neighbouring lane: 16 independent loads per lane instead
+    // of 32 dependent branches.
+    const long f_start = base + step - ((p.frame_len + step - 1) / step) * step;  // = step * (hops - 2) for 400/160
+    const bool frame_ok = f_start >= 0;
+    const long fidx = f_start / step;
+    const int base_mod = (int)(base % ring_len);
+    const int d0 = (int)(f_start - base);                                 // <= 0, >= -ring_len
+    const int first_d = base < (long)ring_len ? -(int)base : -ring_len;   // offsets below it precede the stream (or the ring)
+    auto sample = [&](int s, int d) -> float {
+        int r = base_mod + d;
+        r += r < 0 ? ring_len : 0;
+        const int dc = d < first_d ? first_d : d;  // keep the address in bounds; the value is dropped below
+        const int16_t* ptr = d >= 0 ? hop + (size_t)s * step + d : pcm_ring + (size_t)s * ring_len + (dc == d ? r : 0);
+        const float x = to_unit(*ptr);
+        return d < first_d ? 0.f : x;
+    };
+    cf v[8];
+    bool nza = false, nzb = false;
+    float carry_a = 0.f, carry_b = 0.f;  // sample just before this lane block (lane 63 of the previous block)
+    if (frame_ok) {
+        carry_a = sample(sa, d0 - 1);
+        if (has_b) carry_b = sample(sb, d0 - 1);
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int i = 64 * n1 + lane;
+        float ya = 0.f, yb = 0.f;
+        if (frame_ok && 64 * n1 < p.frame_len) {  // wave-uniform
+            const bool in = i < p.frame_len;
+            const int d = d0 + (in ? i : 0);
+            const bool first = f_start + i == 0;  // the stream's very first sample is not pre-emphasised
+            const float ca = sample(sa, d);
+            float pa = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ca), 0x138, 0xf, 0xf, false));  // wave_shr:1
+            pa = lane == 0 ? carry_a : pa;
+            carry_a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca), 63));
+            ya = in ? (first ? ca : __fsub_rn(ca, __fmul_rn(p.preemph, pa))) : 0.f;
+            if (has_b) {
+                const float cb = sample(sb, d);
+                float pb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cb), 0x138, 0xf, 0xf, false));
+                pb = lane == 0 ? carry_b : pb;
+                carry_b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cb), 63));
+                yb = in ? (first ? cb : __fsub_rn(cb, __fmul_rn(p.preemph, pb))) : 0.f;
+            }
+        }
+        v[n1].x = ya;
+        v[n1].y = yb;
+        nza |= ya != 0.f;
+        nzb |= yb != 0.f;
+    }
+    nza = __any(nza);
+    nzb = __any(nzb);
+    // Append the hop to the rings now, so that the stores complete under the transform: the slots they overwrite,
+    // [base, base + step) mod ring_len, are older than anything the frame read (the ring is one hop longer than the
+    // frame's reach, kws_stream_open), and every read above is earlier in this wavefront's program order.
+    for (int i = lane; i < step; i += 64) {
+        int pos = base_mod + i;
+        pos -= pos >= ring_len ? ring_len : 0;
+        pcm_ring[(size_t)sa * ring_len + pos] = hop[(size_t)sa * step + i];
+        if (has_b) pcm_ring[(size_t)sb * ring_len + pos] = hop[(size_t)sb * step + i];
+    }
+    wave_lds_order();
+    if (frame_ok) {
+        const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
+                                reinterpret_cast<float*>(scr + SCR_LBUF),
+                                dctb, tw2, nfp};
+        const int row = (int)(fidx % p.num_frames);
+        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
+                  feat_ring + ((size_t)sa * p.num_frames + row) * p.numcep,
+                  feat_ring + ((size_t)sb * p.num_frames + row) * p.numcep, lds_out_a);
+    }
+    return frame_ok ? fidx : -1;
 }
 
 }  // namespace

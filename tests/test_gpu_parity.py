@@ -756,6 +756,46 @@ def test_streaming_frames_and_labels(native, dev, e2e_golden, use_graph):
         sp.close()
 
 
+def test_streaming_one_launch_push_agrees_with_the_two_launch_path(native, dev, e2e_golden):
+    """A push that asks for logits from the product DS-CNN is one launch (each stream's new frame is computed in the prologue
+    of its DS-CNN workgroup); a features-only push, and a push under the f32-MFMA pointwise variant, take the separate frame
+    kernel (two streams per packed transform) + the DS-CNN kernel.  Same rings, same hop counts, same logits up to the
+    arithmetic of the variants -- at an odd stream count, across the ring wrap (hop > 99)."""
+    S, hops = 7, 130
+    blob = e2e_golden["he.blob"]
+    pcm = np.random.default_rng(77).integers(-20000, 20000, size=(hops, S, 160), dtype=np.int16)
+    pcm[:, 2] //= 50
+    ctxs = {name: native.Context(dev.index) for name in ("fused", "features_only", "f32_two_launch")}
+    try:
+        for c in ctxs.values():
+            c.use_torch_stream()   # the three pushes of a hop and the copy of the next hop stay in program order
+            c.load_dscnn(blob, 12)
+            c.stream_open(S)
+        ctxs["f32_two_launch"].set_pointwise_math(native.PW_F32)
+        hop = torch.empty((S, 160), dtype=torch.int16, device=dev)
+        logits = {k: torch.empty((S, 12), dtype=torch.float32, device=dev) for k in ctxs}
+        labels = {k: torch.empty((S,), dtype=torch.int32, device=dev) for k in ctxs}
+        rings = {k: torch.empty((S, 99, 10), dtype=torch.float32, device=dev) for k in ctxs}
+        for t in range(hops):
+            hop.copy_(torch.from_numpy(pcm[t]))
+            ctxs["fused"].stream_push_i16(hop, logits["fused"], labels["fused"])
+            ctxs["features_only"].stream_push_i16(hop)
+            ctxs["f32_two_launch"].stream_push_i16(hop, logits["f32_two_launch"], labels["f32_two_launch"])
+            if t in (1, 2, 60, 98, 99, 100, hops - 1):
+                for k, c in ctxs.items():
+                    c.stream_copy_features(rings[k])
+                    c.sync()
+                    assert c.stream_state()[1] == t + 1, k
+                a, b, d = (rings[k].cpu().numpy() for k in ("fused", "features_only", "f32_two_launch"))
+                assert np.array_equal(b, d)                         # the same kernel on the same samples
+                assert np.abs(a - b).max() <= TOL, f"hop {t}"        # one frame vs two frames per packed transform (float32 roundings)
+                la, ld = logits["fused"].cpu().numpy(), logits["f32_two_launch"].cpu().numpy()
+                assert np.abs(la - ld).max() <= 5e-5 * max(1.0, np.abs(ld).max()), f"hop {t}"
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
 def test_streaming_graph_survives_a_weight_reload(dev, e2e_golden):
     """A captured push holds the weight pointers by value: after kws_load_dscnn (StreamingSpotter.load_model) the next
     push must classify with the NEW weights (the graph is re-captured), eager and replayed alike; the feature ring is

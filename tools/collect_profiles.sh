@@ -21,7 +21,7 @@ for W in $WORKLOADS; do
     mfcc-only)       STEPS=200; CMD="python $REPO/bench.py --model mfcc-only --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0"; KERNELS="kws_mfcc_i16_kernel";;
     cnn-trad-fpool3) STEPS=100; CMD="python $REPO/bench.py --model cnn-trad-fpool3 --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0"; KERNELS="kws_mfcc_i16_kernel kws_cnntrad_conv_kernel kws_cnntrad_dense_kernel";;
     ds-cnn-1024)     STEPS=400; CMD="python $REPO/bench.py --batch 1024 --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0 --configs none --no-parity"; KERNELS="kws_mfcc_i16_kernel kws_dscnn_fwd_kernel";;
-    stream)          STEPS=300; CMD="python $REPO/tools/bench_stream.py 64 $STEPS eager"; KERNELS="kws_stream_frame_kernel kws_dscnn_fwd_kernel";;
+    stream)          STEPS=300; CMD="python $REPO/tools/bench_stream.py 64 $STEPS eager"; KERNELS="kws_dscnn_fwd_kernel";;
     *) echo "unknown workload $W"; exit 1;;
   esac
   EXPECT=$((SPIN + WARM + STEPS)); [ "$W" = stream ] && EXPECT=$STEPS
