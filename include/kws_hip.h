@@ -195,8 +195,11 @@ int kws_forward_debug_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_log
 int kws_stream_open(kws_ctx* ctx, int n_streams);
 int kws_stream_close(kws_ctx* ctx);
 /* d_hop: int16 [n_streams, frame_step] new samples; d_logits float32 [n_streams, C] (NULL: features only);
- * d_label int32 [n_streams] or NULL.  A push is two launches (frame kernel, which also advances the hop counter,
- * and DS-CNN); use_graph != 0 replays them as one hipGraph (built on first use for the given pointer triple). */
+ * d_label int32 [n_streams] or NULL.  With logits and the default pointwise math a push is ONE launch: each stream's
+ * workgroup of the DS-CNN kernel computes the stream's new frame in its prologue and the last workgroup advances the hop
+ * counter.  Features-only pushes, and pushes under KWS_PW_F32 / the VALU check, are the frame kernel (which then advances
+ * the counter) followed by the DS-CNN kernel.  use_graph != 0 replays the push as a hipGraph (built on first use for the
+ * given pointer triple). */
 int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
  * by the context) and the number of pushes so far; the newest frame is row (hops - 3) mod num_frames. */
@@ -280,8 +283,9 @@ int kws_spec_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int frame_
 
 /* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
  * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
- * launch count per kernel id since the last kws_prof_reset.  The two kernels of an eager kws_stream_push_i16 are timed
- * too (KWS_K_STREAM_FRAME, KWS_K_DSCNN); a push replayed as a hipGraph is not (events cannot bracket a node). */
+ * launch count per kernel id since the last kws_prof_reset.  The kernels of an eager kws_stream_push_i16 are timed
+ * too (KWS_K_DSCNN for the one-launch push; KWS_K_STREAM_FRAME + KWS_K_DSCNN for the two-launch routes); a push replayed
+ * as a hipGraph is not (events cannot bracket a node). */
 enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_STREAM_FRAME = 4, KWS_K_MFCC_F64 = 5, KWS_K_COUNT = 6 };
 int kws_prof_enable(kws_ctx* ctx, int on);
 int kws_prof_reset(kws_ctx* ctx);
