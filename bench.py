@@ -343,7 +343,7 @@ def hbm_roofline(_native, kid, launches, avg_ms, B, workload):
     return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_BPS / 1e9, "unit": "GB/s",
             "frac": achieved / (PEAK_HBM_BPS / 1e9), "traffic": pmc_traffic(name, workload),
             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-            "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP, "avg_kernel_ms": avg_ms, "launches": launches,
+            "algorithmic_bytes_per_launch": B * BYTES_PER_CLIP, "avg_kernel_ms": avg_ms, "launches": launches, "launches_note": "launches timed with HIP events inside the timed region (every --prof-every-th launch)",
             "note": "algorithmic HBM read (32 000 B per clip) over the kernel's duration against the 8 TB/s spec peak, the "
                     "roofline BASELINE.json declares; the kernel is LDS/VALU-bound (DESIGN.md 4.1): "
                     f"{B / s * MFCC_FLOP_PER_CLIP / 1e12 if s > 0 else 0.0:.1f} TFLOP/s of 157.3 f32"}
@@ -358,7 +358,7 @@ def dscnn_roofline(_native, launches, avg_ms, B, workload="ds-cnn"):
         "kernel": name, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / PEAK_F32_TFLOPS, "traffic": pmc_traffic(name, workload),
         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
-        "algorithmic_bytes_per_launch": B * (99 * 10 * 4 + 52), "avg_kernel_ms": avg_ms, "launches": launches,
+        "algorithmic_bytes_per_launch": B * (99 * 10 * 4 + 52), "avg_kernel_ms": avg_ms, "launches": launches, "launches_note": "launches timed with HIP events inside the timed region (every --prof-every-th launch)",
         "flop_per_clip": DSCNN_FLOP_PER_CLIP,
         "math": "f32 in / f32 out; conv1 and the four 1x1 convolutions run on v_mfma_f32_32x32x16_bf16 as exact "
                 "three-way bf16 splits (6 MFMAs per f32 product, f32 accumulate); achieved/peak/frac price the ALGORITHMIC "
@@ -382,7 +382,7 @@ def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
     for _ in range(args.spinup + args.warmup):
         step()
     ctx.sync()
-    ctx.prof_enable(True)
+    ctx.prof_enable(args.prof_every)
     ctx.prof_reset()
     steps = max(10, args.config_steps // 5) if precise else args.config_steps
     t0 = time.perf_counter()
@@ -429,7 +429,7 @@ def leg_cnn_trad(args, _native, torch, dev, B, cpu_n):
     for _ in range(max(10, args.spinup // 3) + 3):
         step()
     ctx.sync()
-    ctx.prof_enable(True)
+    ctx.prof_enable(args.prof_every)
     ctx.prof_reset()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -491,7 +491,7 @@ def leg_dscnn_shard(args, _native, torch, dev, blob, B):
     for _ in range(4 * args.spinup + args.warmup):  # a 1024-clip step is a quarter of the headline's: same spin-up time
         step()
     ctx.sync()
-    ctx.prof_enable(True)
+    ctx.prof_enable(args.prof_every)
     ctx.prof_reset()
     steps = args.config_steps * 2
     t0 = time.perf_counter()
@@ -534,7 +534,7 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
             hop.copy_(pcm[t])
             torch.cuda.synchronize()
             if t == hops - extra and extra:
-                ctx.prof_enable(True)
+                ctx.prof_enable(args.prof_every)
                 ctx.prof_reset()
             t0 = time.perf_counter()
             ctx.stream_push_i16(hop, logits, labels, use_graph=use_graph)
@@ -707,7 +707,7 @@ def worker(args) -> int:
         for _ in range(args.spinup + args.warmup):
             step()
         ctx.sync()
-        ctx.prof_enable(True)
+        ctx.prof_enable(args.prof_every)
         ctx.prof_reset()
 
     t_local0 = time.perf_counter()
@@ -872,6 +872,9 @@ def parse_args(argv=None):
                     help="f32: the fast front end (default, the headline); f64: KWS_FE_F64, float64 after framing as psf computes it")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the extra launch on the golden clips after the timed region (profile runs: exact launch counts)")
+    ap.add_argument("--prof-every", type=int, default=8,
+                    help="HIP events around every n-th launch of each kernel inside the timed region (roofline.avg_kernel_ms); "
+                         "a pair per launch costs the stream ~7 us = 2 %% of a 4096-clip step (tools/prof_overhead.py)")
     ap.add_argument("--selftest-cpu", action="store_true", help=argparse.SUPPRESS)  # launcher rehearsal on CPU (gloo), tests only
     return ap.parse_args(argv)
 

@@ -281,9 +281,11 @@ int kws_spec_f32(kws_ctx* ctx, const float* d_frames, int num_frames, int frame_
 
 /* ---- measurement --------------------------------------------------------------------------- */
 
-/* Per-kernel device timing with HIP events on the context's stream.  While enabled every kernel
- * launch is bracketed by events; kws_prof_read synchronises and returns the summed milliseconds and
- * launch count per kernel id since the last kws_prof_reset.  The kernels of an eager kws_stream_push_i16 are timed
+/* Per-kernel device timing with HIP events on the context's stream.  kws_prof_enable(ctx, on): 0 = off, 1 = every
+ * kernel launch is bracketed by events, n > 1 = every n-th launch of each kernel id is (a pair of events costs the
+ * stream ~7 us: 2 % of a 4096-clip step, 8 % of a 1024-clip one, when every launch carries one); kws_prof_read
+ * synchronises and returns the summed milliseconds and the number of TIMED launches per kernel id since the last
+ * kws_prof_reset.  The kernels of an eager kws_stream_push_i16 are timed
  * too (KWS_K_DSCNN for the one-launch push; KWS_K_STREAM_FRAME + KWS_K_DSCNN for the two-launch routes); a push replayed
  * as a hipGraph is not (events cannot bracket a node). */
 enum { KWS_K_MFCC = 0, KWS_K_DSCNN = 1, KWS_K_CNNTRAD_CONV = 2, KWS_K_CNNTRAD_DENSE = 3, KWS_K_STREAM_FRAME = 4, KWS_K_MFCC_F64 = 5, KWS_K_COUNT = 6 };

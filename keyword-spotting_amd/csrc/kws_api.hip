@@ -157,6 +157,7 @@ struct ProfScope {
     hipEvent_t stop = nullptr;
     ProfScope(kws_ctx* c_, int id_) : c(c_), id(id_) {
         if (!c->prof) return;
+        if (c->prof_seen[id]++ % (unsigned)c->prof_every != 0) return;  // sampling: events around every launch cost ~7 us of stream time each
         if (c->ev_used[id] == c->ev[id].size()) {
             kws_ctx::EvPair p{};
             if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
@@ -1163,6 +1164,7 @@ int kws_spec_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame_le
 int kws_prof_enable(kws_ctx* c, int on) {
     if (!c) return KWS_EINVAL;
     c->prof = on != 0;
+    c->prof_every = on > 1 ? on : 1;
     return KWS_OK;
 }
 
@@ -1188,6 +1190,7 @@ int kws_prof_reset(kws_ctx* c) {
     for (int k = 0; k < KWS_K_COUNT; ++k) {
         c->ms_total[k] = 0;
         c->launches[k] = 0;
+        c->prof_seen[k] = 0;
     }
     return rc;
 }

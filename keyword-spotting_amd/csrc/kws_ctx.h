@@ -66,6 +66,8 @@ struct kws_ctx {
 
     // profiling
     bool prof = false;
+    int prof_every = 1;                    // bracket every prof_every-th launch of a kernel id (kws_prof_enable)
+    unsigned prof_seen[KWS_K_COUNT] = {};  // launches per kernel id since kws_prof_reset, timed or not
     struct EvPair {
         hipEvent_t a, b;
     };

@@ -341,7 +341,8 @@ class Context:
 
     # -- measurement ----------------------------------------------------------------------------
     def prof_enable(self, on=True):
-        self._check(self._lib.kws_prof_enable(self._h, 1 if on else 0))
+        """False/0 = off, True/1 = time every kernel launch, n > 1 = time every n-th launch of each kernel."""
+        self._check(self._lib.kws_prof_enable(self._h, int(on)))
 
     def prof_reset(self):
         self._check(self._lib.kws_prof_reset(self._h))
