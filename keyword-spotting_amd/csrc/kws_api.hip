@@ -11,7 +11,8 @@
 namespace kws {
 
 const char* const kKernelNames[KWS_K_COUNT] = {"kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel",
-                                               "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel", "kws_mfcc_f64_kernel"};
+                                               "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel", "kws_mfcc_f64_kernel",
+                                               "kws_mfcc_refine_kernel"};
 
 // ------------------------------------------------------------------------------------------------
 // Host tables (double precision, then rounded once to float32).
@@ -227,6 +228,7 @@ void kws_destroy(kws_ctx* c) {
         }
     if (c->d_fe) (void)hipFree(c->d_fe);
     if (c->d_spec_tw64) (void)hipFree(c->d_spec_tw64);
+    if (c->d_refine) (void)hipFree(c->d_refine);
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_cnntrad) (void)hipFree(c->d_cnntrad);
     if (c->d_conv_ws) (void)hipFree(c->d_conv_ws);
@@ -396,6 +398,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     p.vec_ok = (n_samples % 8 == 0) && ((MFCC_FRAMES_PER_WG * frame_step) % 8 == 0);
     p.nfft = nfft;
     p.log2_nfft = log2n;
+    p.refine_span = c->refine_span;
     c->sample_rate = sample_rate;
     c->nfft = nfft;
     c->ceplifter = ceplifter;
@@ -414,6 +417,30 @@ int kws_set_frontend_math(kws_ctx* c, int math) {
 int kws_frontend_math(kws_ctx* c) {
     if (!c || !c->fe_ready) return KWS_EINVAL;
     return (c->fe_math == KWS_FE_F64 || !c->fe_fast_ok) ? KWS_FE_F64 : KWS_FE_F32;
+}
+
+int kws_set_frontend_refine(kws_ctx* c, float log_span) {
+    if (!c) return KWS_EINVAL;
+    if (!(log_span == log_span)) return fail(c, KWS_EINVAL, "kws_set_frontend_refine: log_span is NaN");
+    c->refine_span = log_span > 0.f ? log_span : 0.f;
+    c->fp.refine_span = c->refine_span;
+    if (c->stream_graph) {  // a captured push holds the front-end parameters by value
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        drop_stream_graph(c);
+    }
+    return KWS_OK;
+}
+
+int kws_frontend_stats(kws_ctx* c, uint64_t* frames_total, uint64_t* frames_refined, int* last_call_refined) {
+    if (!c) return KWS_EINVAL;
+    int ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_refine) HIP_TRY(c, hipMemcpy(ctr, c->d_refine, sizeof ctr, hipMemcpyDeviceToHost));
+    if (frames_total) *frames_total = c->frames_seen;
+    if (frames_refined) *frames_refined = ((uint64_t)(uint32_t)ctr[3] << 32 | (uint32_t)ctr[2]) + (uint64_t)(uint32_t)ctr[5];
+    if (last_call_refined) *last_call_refined = ctr[4];
+    return KWS_OK;
 }
 
 int kws_frontend_shape(kws_ctx* c, int* num_frames, int* numcep) {
@@ -544,10 +571,35 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     return KWS_OK;
 }
 
+// Worklist of the selective refinement for batches of up to B clips: int[8] counters + one entry per frame.  The counters
+// (running totals included) move to the new allocation.
+static int ensure_refine(kws_ctx* c, int B) {
+    const size_t frames = (size_t)B * ((c->fp.num_frames + 1) / 2);  // one entry per frame pair
+    if (frames > 0x1fffffffu) return fail(c, KWS_EUNSUPPORTED, "refinement worklist: more than 2^29 frame pairs in one call");
+    if (c->d_refine && (int)frames <= c->refine_cap) return KWS_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(int) * (8 + frames)) != hipSuccess)
+        return fail(c, KWS_ENOMEM, "refinement worklist: device allocation failed");
+    hipError_t e = c->d_refine ? hipMemcpy(d, c->d_refine, sizeof(int) * 8, hipMemcpyDeviceToDevice) : hipMemset(d, 0, sizeof(int) * 8);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail_hip(c, e, "refinement worklist");
+    }
+    if (c->d_refine) (void)hipFree(c->d_refine);
+    c->d_refine = d;
+    c->refine_cap = (int)frames;
+    return KWS_OK;
+}
+
 int kws_reserve(kws_ctx* c, int max_batch) {
     if (!c) return KWS_EINVAL;
     if (max_batch <= 0) return fail(c, KWS_EINVAL, "kws_reserve: max_batch must be positive");
     if (!c->fe_ready) return fail(c, KWS_ESTATE, "front end not configured");
+    if (c->refine_span > 0.f && c->fe_fast_ok) {
+        int rc = ensure_refine(c, max_batch);
+        if (rc) return rc;
+    }
     const size_t need = (size_t)max_batch * c->fp.num_frames * c->fp.numcep;
     if (need <= c->feat_ws_floats) return KWS_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -581,6 +633,19 @@ int kws_mfcc_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_out) {
         HIP_TRY(c, launch_mfcc_f64(c->stream, p, c->ft, d_wav, B, d_out));
         return KWS_OK;
     }
+    c->frames_seen += (unsigned long long)B * p.num_frames;
+    if (p.refine_span > 0.f) {
+        rc = ensure_refine(c, B);
+        if (rc) return rc;
+        const RefineList rl = {c->d_refine, c->d_refine + 8, c->refine_cap, 0};
+        {
+            ProfScope ps(c, KWS_K_MFCC);
+            HIP_TRY(c, launch_mfcc_flag(c->stream, p, c->ft, d_wav, B, d_out, rl));
+        }
+        ProfScope ps(c, KWS_K_MFCC_REFINE);
+        HIP_TRY(c, launch_mfcc_refine(c->stream, p, c->ft, d_wav, d_out, rl));
+        return KWS_OK;
+    }
     ProfScope ps(c, KWS_K_MFCC);
     HIP_TRY(c, launch_mfcc(c->stream, p, c->ft, d_wav, B, d_out));
     return KWS_OK;
@@ -595,6 +660,19 @@ int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
     if (c->fe_math == KWS_FE_F64 || !c->fe_fast_ok) {
         ProfScope ps(c, KWS_K_MFCC_F64);
         HIP_TRY(c, launch_mfcc_f64_f32in(c->stream, c->fp, c->ft, d_wav, B, d_out));
+        return KWS_OK;
+    }
+    c->frames_seen += (unsigned long long)B * c->fp.num_frames;
+    if (c->fp.refine_span > 0.f) {
+        rc = ensure_refine(c, B);
+        if (rc) return rc;
+        const RefineList rl = {c->d_refine, c->d_refine + 8, c->refine_cap, 0};
+        {
+            ProfScope ps(c, KWS_K_MFCC);
+            HIP_TRY(c, launch_mfcc_f32_flag(c->stream, c->fp, c->ft, d_wav, B, d_out, rl));
+        }
+        ProfScope ps(c, KWS_K_MFCC_REFINE);
+        HIP_TRY(c, launch_mfcc_refine_f32in(c->stream, c->fp, c->ft, d_wav, d_out, rl));
         return KWS_OK;
     }
     ProfScope ps(c, KWS_K_MFCC);
@@ -745,6 +823,10 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
         return fail(c, KWS_ENOMEM, "kws_stream_open: device allocation failed");
     }
     c->n_streams = n_streams;
+    if (c->refine_span > 0.f) {  // the pushes count the frames they redo in float64 in the refinement counters
+        int rc = ensure_refine(c, 1);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, 2 * sizeof(int), c->stream));
@@ -1003,7 +1085,7 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         c->prof = was && timed;
         ProfScope ps(c, KWS_K_DSCNN);
         c->prof = was;
-        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops};
+        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine};
         return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label);
     }
     {
@@ -1012,7 +1094,7 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         ProfScope ps(c, KWS_K_STREAM_FRAME);
         c->prof = was;
         e = launch_stream_frame(c->stream, c->fp, c->ft, d_hop, c->n_streams, c->d_pcm_ring, c->ring_len, c->d_feat_ring,
-                                c->d_hops);
+                                c->d_hops, c->d_refine);
     }
     if (e != hipSuccess) return e;
     if (d_logits) {

@@ -27,6 +27,11 @@ struct kws_ctx {
     FrontendTables ft{};
     double* d_spec_tw64 = nullptr;  // float64 twiddles of kws_spec_f32's last transform length
     int spec_nfft = 0;
+    // selective float64 refinement of the float32 front end (kws_set_frontend_refine): worklist + counters
+    float refine_span = KWS_FE_REFINE_SPAN_DEFAULT;
+    int* d_refine = nullptr;          // int[8] counters followed by the list, one allocation
+    int refine_cap = 0;               // frames the list holds
+    unsigned long long frames_seen = 0;  // frames through the float32 kernels since kws_create
 
     // model
     float* d_model = nullptr;

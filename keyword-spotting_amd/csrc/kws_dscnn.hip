@@ -862,7 +862,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         if (wv == 0)  // first: its sample and table loads join the feature loads already in flight
             stream_frame_wave(sp.p, sp.t, sp.hop, clip, clip, false, sp.pcm_ring, sp.ring_len, const_cast<float*>(feat), hops_before,
                               reinterpret_cast<unsigned char*>(lds + OFF_Z2), lane,
-                              row_new >= 0 ? featp + (row_new + 2) * FEAT_W + 2 : nullptr);
+                              row_new >= 0 ? featp + (row_new + 2) * FEAT_W + 2 : nullptr, sp.refine_ctr);
         for (int i = tid; i < FEAT_H * FEAT_W; i += NT) {
             const int r = i / FEAT_W - 2, c = i % FEAT_W - 2;
             if (!((unsigned)r < (unsigned)IN_T && (unsigned)c < (unsigned)IN_F)) featp[i] = 0.f;

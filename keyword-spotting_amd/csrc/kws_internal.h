@@ -44,6 +44,20 @@ struct FrontendParams {
     int vec_ok;            // 1 -> every workgroup's first sample is 16-byte aligned (vector PCM loads legal)
     int nfft;              // transform length (the float32 kernel is built for 512; the float64 kernel takes any)
     int log2_nfft;         // log2(nfft) when nfft is a power of two, else 0 (float64 kernel: FFT vs direct DFT)
+    float refine_span;     // float32 kernels: a frame whose log-mel values span more than this is redone in float64 (0: never)
+};
+
+// Worklist of the selective float64 refinement: the float32 MFCC kernel appends, per frame pair with a
+// flagged frame, (global pair index << 2 | mask of flagged frames), global pair index = clip * ceil(num_frames / 2) +
+// frame / 2; the refinement kernel consumes the list and clears the counters.
+// ctr: int[8], 8-byte aligned = {entries listed by the running call, frames flagged by it (the two are bumped by ONE 64-bit
+// atomic), rows rewritten in total (low, high 32 bits), rows rewritten by the last completed call, frames redone in float64
+// by streaming pushes, finished refinement workgroups, 0}.
+struct RefineList {
+    int* ctr;
+    int* list;
+    int cap;       // entries list can hold (frame pairs of the largest batch reserved); 0 with ctr == nullptr: flagging off
+    int clip0;     // index of the launch's first clip inside the call's batch (batches beyond 65535 clips are split)
 };
 
 // Device tables of the front end (all float32 unless noted), built on the host in double.
@@ -83,6 +97,16 @@ hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTab
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t,
                            const float* d_wav, int B, float* d_out);
 size_t mfcc_lds_bytes(const FrontendParams& p);
+// The float32 kernels with flagging: frames over p.refine_span are appended to rl (rl.ctr == nullptr: no flagging).
+hipError_t launch_mfcc_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B, float* d_out,
+                            const RefineList& rl);
+hipError_t launch_mfcc_f32_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
+                                float* d_out, const RefineList& rl);
+// Float64 recomputation of the listed frames, in place in d_out (same d_wav / d_out as the float32 launch before it).
+hipError_t launch_mfcc_refine(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, float* d_out,
+                              const RefineList& rl);
+hipError_t launch_mfcc_refine_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, float* d_out,
+                                    const RefineList& rl);
 // The float64 front end: any nfft (power of two up to 4096: FFT; otherwise up to 2048: direct DFT), any frame length.
 hipError_t launch_mfcc_f64(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B, float* d_out);
 hipError_t launch_mfcc_f64_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
@@ -92,7 +116,7 @@ hipError_t launch_spec_f64(hipStream_t s, const double* d_tw64, const float* d_f
 // Streaming: one hop of frame_step new samples per stream -> one new MFCC frame per stream in the feature ring.
 // d_hops: int[2] = {hops pushed so far, finished-workgroup counter}; the kernel advances the hop count itself.
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
-                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops);
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops, int* d_refine_ctr);
 // Training-time augmentation on the device (time shift, silence, background mix).
 hipError_t launch_augment(hipStream_t s, const int16_t* d_wav, int B, int n, const int32_t* d_shift, const float* d_bg,
                           int bg_len, const int32_t* d_bg_off, const float* d_bg_vol, const uint8_t* d_silence,
@@ -138,6 +162,7 @@ struct StreamPush {
     int16_t* pcm_ring;       // [n_streams][ring_len]
     int ring_len;
     int* hops;
+    int* refine_ctr;         // counters of the selective refinement (RefineList::ctr; [5] counts frames redone by pushes) or NULL
 };
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
                                float* d_logits, int32_t* d_label);

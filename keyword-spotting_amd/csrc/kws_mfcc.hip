@@ -33,7 +33,7 @@ namespace {
 // by a lane bound and block 7 is zero -- no loads or selects for it, and the zeros fold through the first butterflies.
 template <typename T, bool TAIL6>
 __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const FrontendTables& t, const T* __restrict__ wav,
-                                          float* __restrict__ out) {
+                                          float* __restrict__ out, const RefineList& rl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // workgroup-shared part (every offset a multiple of 16 bytes)
     const int nfp = (p.nfilt + 3) & ~3;                        // DCT rows padded to float4
@@ -147,9 +147,17 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
         }
         const bool nza = __any((ora << 1) != 0u);
         const bool nzb = __any((orb << 1) != 0u);
-        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
-                  out + ((size_t)clip * p.num_frames + fa) * p.numcep,
-                  out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
+        const uint32_t flags = mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
+                                         out + ((size_t)clip * p.num_frames + fa) * p.numcep,
+                                         out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
+        // a frame the float32 arithmetic cannot hold to 1e-4 (rare; wave-uniform): the pair goes onto the refinement
+        // kernel's worklist with the mask of its flagged frames
+        // (one 64-bit atomic: entries in the low word -- its old value is the slot --, flagged frames in the high word)
+        if (flags && rl.ctr && lane == 0) {
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(rl.ctr), 1ull | ((unsigned long long)__builtin_popcount(flags) << 32));
+            const int at = (int)(unsigned)old;
+            if (at < rl.cap) rl.list[at] = (int)((((unsigned)(rl.clip0 + clip) * (unsigned)((p.num_frames + 1) / 2) + (unsigned)(fa >> 1)) << 2) | flags);
+        }
         wave_lds_order();
     }
 }
@@ -163,23 +171,23 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
 // takes every other frame length up to 512 (one kernel with both bodies spills registers).
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
-                                                                    float* __restrict__ out) {
-    mfcc_body<int16_t, true>(p, t, wav, out);
+                                                                    float* __restrict__ out, RefineList rl) {
+    mfcc_body<int16_t, true>(p, t, wav, out, rl);
 }
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_f32_kernel(FrontendParams p, FrontendTables t,
                                                                     const float* __restrict__ wav,
-                                                                    float* __restrict__ out) {
-    mfcc_body<float, true>(p, t, wav, out);
+                                                                    float* __restrict__ out, RefineList rl) {
+    mfcc_body<float, true>(p, t, wav, out, rl);
 }
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_any_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
-                                                                    float* __restrict__ out) {
-    mfcc_body<int16_t, false>(p, t, wav, out);
+                                                                    float* __restrict__ out, RefineList rl) {
+    mfcc_body<int16_t, false>(p, t, wav, out, rl);
 }
 __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_f32_any_kernel(FrontendParams p, FrontendTables t,
                                                                     const float* __restrict__ wav,
-                                                                    float* __restrict__ out) {
-    mfcc_body<float, false>(p, t, wav, out);
+                                                                    float* __restrict__ out, RefineList rl) {
+    mfcc_body<float, false>(p, t, wav, out, rl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,12 +259,12 @@ __global__ __launch_bounds__(64) void kws_stream_frame_kernel(FrontendParams p, 
                                                               const int16_t* __restrict__ hop, int n_streams,
                                                               int16_t* __restrict__ pcm_ring, int ring_len,
                                                               float* __restrict__ feat_ring,
-                                                              int* __restrict__ hops_ptr) {
+                                                              int* __restrict__ hops_ptr, int* refine_ctr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int sa = 2 * blockIdx.x, sb = sa + 1;
     const int hops = *hops_ptr;
-    stream_frame_wave(p, t, hop, sa, sb, sb < n_streams, pcm_ring, ring_len, feat_ring, hops, smem, lane, nullptr);
+    stream_frame_wave(p, t, hop, sa, sb, sb < n_streams, pcm_ring, ring_len, feat_ring, hops, smem, lane, nullptr, refine_ctr);
     // hop counter: every workgroup read hops_ptr[0] at its start (its value fed every address above, so that load is
     // long complete); the workgroup that finishes last advances it (hops_ptr[1] counts finished workgroups).  No fence:
     // the counter orders nothing inside this launch, and the kernel boundary publishes it to the next one.
@@ -303,7 +311,7 @@ size_t mfcc_lds_bytes(const FrontendParams& p) {
 
 template <typename T, typename K>
 static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p, const FrontendTables& t, const T* d_wav,
-                                int B, float* d_out) {
+                                int B, float* d_out, RefineList rl) {
     dim3 grid((p.num_frames + MFCC_FRAMES_PER_WG - 1) / MFCC_FRAMES_PER_WG, B);
     const size_t lds = mfcc_lds_bytes(p);
     if (lds > 64 * 1024) {  // geometries (or experiment shapes) beyond the default dynamic-LDS limit opt in per kernel
@@ -314,29 +322,37 @@ static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p
     for (int b0 = 0; b0 < B; b0 += 65535) {
         const int nb = (B - b0 < 65535) ? (B - b0) : 65535;
         grid.y = nb;
+        rl.clip0 = b0;
         hipLaunchKernelGGL(kernel, grid, dim3(MFCC_THREADS), lds, s, p, t, d_wav + (size_t)b0 * p.n_samples,
-                           d_out + (size_t)b0 * p.num_frames * p.numcep);
+                           d_out + (size_t)b0 * p.num_frames * p.numcep, rl);
     }
     return hipGetLastError();
 }
 
+hipError_t launch_mfcc_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B,
+                            float* d_out, const RefineList& rl) {
+    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
+    return launch_mfcc_t(tail6 ? kws_mfcc_i16_kernel : kws_mfcc_i16_any_kernel, s, p, t, d_wav, B, d_out, rl);
+}
+hipError_t launch_mfcc_f32_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
+                                float* d_out, const RefineList& rl) {
+    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
+    return launch_mfcc_t(tail6 ? kws_mfcc_f32_kernel : kws_mfcc_f32_any_kernel, s, p, t, d_wav, B, d_out, rl);
+}
 hipError_t launch_mfcc(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B,
                        float* d_out) {
-    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
-    return launch_mfcc_t(tail6 ? kws_mfcc_i16_kernel : kws_mfcc_i16_any_kernel, s, p, t, d_wav, B, d_out);
+    return launch_mfcc_flag(s, p, t, d_wav, B, d_out, RefineList{});
 }
 hipError_t launch_mfcc_f32(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
                            float* d_out) {
-    const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
-    return launch_mfcc_t(tail6 ? kws_mfcc_f32_kernel : kws_mfcc_f32_any_kernel, s, p, t, d_wav, B, d_out);
+    return launch_mfcc_f32_flag(s, p, t, d_wav, B, d_out, RefineList{});
 }
 
 hipError_t launch_stream_frame(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_hop,
-                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops) {
-    const int nfp = (p.nfilt + 3) & ~3;
-    const size_t lds = sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES;
+                               int n_streams, int16_t* d_pcm_ring, int ring_len, float* d_feat_ring, int* d_hops, int* d_refine_ctr) {
+    const size_t lds = stream_frame_lds_bytes(p);
     hipLaunchKernelGGL(kws_stream_frame_kernel, dim3((n_streams + 1) / 2), dim3(64), lds, s, p, t, d_hop, n_streams,
-                       d_pcm_ring, ring_len, d_feat_ring, d_hops);
+                       d_pcm_ring, ring_len, d_feat_ring, d_hops, d_refine_ctr);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 // See kws_mfcc.hip for the work decomposition and the numerics.
 #pragma once
 #include "kws_internal.h"
+#include "kws_mfcc_f64_dev.h"
 
 namespace kws {
 namespace {
@@ -429,10 +430,44 @@ __device__ __forceinline__ void segment_suffix_sums(float& a, float& b, float& c
             : "v"(m.m4));
 }
 
+// Precision flag of the float32 front end.  A float32 transform leaves rounding noise ~138 dB below a
+// frame's strongest component, so a mel band far below the strongest one carries a large relative error, which log, DCT and
+// lifter turn into a cepstral error: measured against the float64 reference, every frame whose log-mel values span less
+// than 12 (52 dB) stays within 6e-5, while a clean tone over a quiet floor (span 19) misses by up to 6e-4.  The span is
+// therefore taken here, from the log-mel values the lanes hold anyway, and frames over the threshold are redone in
+// float64 by the refinement kernel (batched) or on the spot (streaming).
+// v: the frame's centred log-mel value in lanes of the frame, 0 (= filter 0's value) in the others.  FULL = false: two
+// frames, one per 32-lane half -- the result is valid in lanes 31 and 63; FULL = true: one frame over 64 lanes, lane 63.
+// Returns the ballot of (max - min > thr).  Running maximum and minimum by DPP row scans; a lane without a source keeps
+// its value (no bound_ctrl: zeros shifted in would win a maximum of negative logs); the two chains alternate and one
+// s_nop separates a write from the DPP read of the same register (VALU -> DPP: two wait states, hidden from the compiler).
+template <bool FULL>
+__device__ __forceinline__ unsigned long long span_over(float v, float thr) {
+    float mx = v, mn = v;
+#define KWS_MM_STEP(ctrl)                                      \
+    "v_max_f32_dpp %0, %0, %0 " ctrl "\n\t"                    \
+    "v_min_f32_dpp %1, %1, %1 " ctrl "\n\t"                    \
+    "s_nop 0\n\t"
+    asm("s_nop 1\n\t"
+        KWS_MM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1, 3: lane 15 of the row below joins
+        : "+v"(mx), "+v"(mn));
+    if constexpr (FULL)
+        asm("s_nop 1\n\t"
+            KWS_MM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")  // rows 2, 3: lane 31 joins
+            : "+v"(mx), "+v"(mn));
+#undef KWS_MM_STEP
+    return __ballot(mx - mn > thr);
+}
+
 // One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
 // FFT -> split -> power -> sparse mel -> log -> DCT x lifter, c0 = log(frame energy).
 // out_a / out_b: rows of numcep floats for frame a / b (out_b is not touched when has_b is false).
-__device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
+// Returns the precision flags of the pair (wave-uniform): bit 0 = frame a, bit 1 = frame b spans more than p.refine_span.
+__device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
                                           const PairScratch& sc, const cf (&t1)[8], const MelLane& ml, int lane,
                                           float* __restrict__ out_a, float* __restrict__ out_b,
                                           float* lds_out_a = nullptr) {
@@ -449,7 +484,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
 #endif
 #if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP <= 1   // counter attribution (tools/pmc_mfcc_variant.sh): stop after the transform; wrong results
     if (lane < p.numcep) out_a[lane] = v[0].x + v[1].y + v[2].x + v[3].y + v[4].x + v[5].y + v[6].x + v[7].y + lv.pow_a;
-    return;
+    return 0u;
 #endif
 
     float ea, eb;
@@ -457,7 +492,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     wave_sum2(ea, eb);
 #if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 2    // stop after the power spectrum
     if (lane < p.numcep) out_a[lane] = ea + eb + pbuf[lane].x;
-    return;
+    return 0u;
 #endif
 
     // sparse mel: this lane's chunk of <= 8 bins is one contiguous 64-byte run of the power buffer (four
@@ -483,6 +518,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
     // j fetches its two totals through the LDS crossbar (ds_bpermute: no memory, no bank conflicts).
     segment_suffix_sums(ra, fa_, rb, fb_, ml);
     float ma, mb;
+    uint32_t flags = 0u;
     {
         const int r0 = gth & 255, nr = (gth >> 8) & 255, q0 = (gth >> 16) & 255, nq = gth >> 24;
         const float gra = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * r0, __builtin_bit_cast(int, ra)));
@@ -503,16 +539,25 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
             mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), 32));
 #if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 3    // stop after mel + log
             if (lane < p.numcep) out_a[lane] = l + ea + eb;
-            return;
+            return 0u;
 #endif
             const int f = lane >> 5, j = lane & 31;
-            lbuf[64 * f + j] = j < p.nfilt ? l - (f ? mb : ma) : 0.f;
+            const float cv = j < p.nfilt ? l - (f ? mb : ma) : 0.f;
+            lbuf[64 * f + j] = cv;
+            if (p.refine_span > 0.f) {  // wave-uniform
+                const unsigned long long over = span_over<false>(cv, p.refine_span);
+                flags = (uint32_t)((over >> 31) & 1u) | ((uint32_t)((over >> 63) & 1u) << 1);
+            }
         } else {
             const float la = logf(sa == 0.f ? PSF_EPS : sa), lb = logf(sb == 0.f ? PSF_EPS : sb);
             ma = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, la)));
             mb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lb)));
-            lbuf[lane] = lane < p.nfilt ? la - ma : 0.f;
-            lbuf[64 + lane] = lane < p.nfilt ? lb - mb : 0.f;
+            const float cva = lane < p.nfilt ? la - ma : 0.f, cvb = lane < p.nfilt ? lb - mb : 0.f;
+            lbuf[lane] = cva;
+            lbuf[64 + lane] = cvb;
+            if (p.refine_span > 0.f)
+                flags = (uint32_t)((span_over<true>(cva, p.refine_span) >> 63) & 1u) |
+                        ((uint32_t)((span_over<true>(cvb, p.refine_span) >> 63) & 1u) << 1);
         }
     }
     wave_lds_order();
@@ -567,6 +612,7 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
         }
     }
     wave_lds_order();
+    return has_b ? flags : (flags & 1u);
 }
 
 
@@ -579,15 +625,37 @@ __device__ __forceinline__ void mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool h
 // cepstra go to row (frame index mod num_frames) of each stream's feature ring and, when lds_out_a is not null, stream
 // sa's also to those numcep floats in LDS.  smem: stream_frame_lds_bytes(p) bytes of LDS, private to the wavefront.
 // Returns the frame's index in the continuous signal, or -1 while the stream is younger than one frame.
-__device__ __forceinline__ size_t stream_frame_lds_bytes(const FrontendParams& p) {
+constexpr int STREAM_F64_BYTES = 16 * NFFT + 8 * 128;  // float64 redo of a flagged frame: the transform buffer and two log-mel vectors
+__host__ __device__ __forceinline__ size_t stream_frame_lds_bytes(const FrontendParams& p) {
     const int nfp = (p.nfilt + 3) & ~3;
-    return sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES;
+    return sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + SCR_BYTES + STREAM_F64_BYTES;
+}
+
+// float64 recomputation of ONE frame (the streaming push's flagged frames): get(i) = pre-emphasised sample
+// i < frame_len, float32 as the reference forms it.  The frame rides alone in its transform (imaginary half empty), the
+// tables are read where they lie in global memory -- a rare path.  X: NFFT d2 of LDS, L: 128 doubles, private to the wave.
+template <typename F>
+__device__ __forceinline__ void f64_redo_frame(const FrontendParams& p, const FrontendTables& t, d2* X, double* L, F&& get,
+                                               float* __restrict__ out, float* lds_out, int lane) {
+    bool nz = false;
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int i = 64 * n1 + lane;
+        const float y = i < p.frame_len ? get(i) : 0.f;
+        nz |= y != 0.f;
+        X[sw512(i)] = d2{(double)y, 0.0};
+    }
+    nz = __any(nz);
+    wave_order();
+    spectrum_pair<true, NFFT>(X, X, reinterpret_cast<const d2*>(t.tw64), NFFT, 9, p.frame_len, 1.0 / (double)NFFT, lane);
+    const F64Tabs tb = {reinterpret_cast<const d2*>(t.tw64), t.mel_w64, t.dct64, t.mel_edges};
+    f64_tail<NBINS>(p, tb, NBINS, X, L, nz, false, false, out, out, lds_out, lane);
 }
 __device__ __forceinline__ long stream_frame_wave(const FrontendParams& p, const FrontendTables& t,
                                                   const int16_t* __restrict__ hop, int sa, int sb, bool has_b,
                                                   int16_t* __restrict__ pcm_ring, int ring_len,
                                                   float* __restrict__ feat_ring, int hops, unsigned char* smem, int lane,
-                                                  float* lds_out_a) {
+                                                  float* lds_out_a, int* refine_ctr = nullptr) {
     const int nfp = (p.nfilt + 3) & ~3;
     float* dctb = reinterpret_cast<float*>(smem);
     cf* tw2 = reinterpret_cast<cf*>(dctb + ((p.numcep * nfp + 3) & ~3));
@@ -682,9 +750,23 @@ __device__ __forceinline__ long stream_frame_wave(const FrontendParams& p, const
                                 reinterpret_cast<float*>(scr + SCR_LBUF),
                                 dctb, tw2, nfp};
         const int row = (int)(fidx % p.num_frames);
-        mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
-                  feat_ring + ((size_t)sa * p.num_frames + row) * p.numcep,
-                  feat_ring + ((size_t)sb * p.num_frames + row) * p.numcep, lds_out_a);
+        float* out_a = feat_ring + ((size_t)sa * p.num_frames + row) * p.numcep;
+        float* out_b = feat_ring + ((size_t)sb * p.num_frames + row) * p.numcep;
+        const uint32_t flags = mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane, out_a, out_b, lds_out_a);
+        if (flags) {  // wave-uniform and rare: a frame float32 cannot hold to 1e-4 is redone in float64, here and now
+            // The hop is in the ring by now (the append above), older samples were never overwritten: gather again.
+            d2* X = reinterpret_cast<d2*>(scr + SCR_BYTES);
+            double* L = reinterpret_cast<double*>(scr + SCR_BYTES + 16 * NFFT);
+            auto frame_of = [&](int s) {
+                return [&, s](int i) -> float {
+                    const float cur = sample(s, d0 + i);
+                    return f_start + i == 0 ? cur : __fsub_rn(cur, __fmul_rn(p.preemph, sample(s, d0 + i - 1)));
+                };
+            };
+            if (flags & 1u) f64_redo_frame(p, t, X, L, frame_of(sa), out_a, lds_out_a, lane);
+            if (flags & 2u) f64_redo_frame(p, t, X, L, frame_of(sb), out_b, nullptr, lane);
+            if (refine_ctr && lane == 0) atomicAdd(refine_ctr + 5, (int)__builtin_popcount(flags));
+        }
     }
     return frame_ok ? fidx : -1;
 }

@@ -19,7 +19,8 @@ from kws.common.errors import AudioProcessingError, KWSError, ModelError
 LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME, KWS_K_MFCC_F64 = 0, 1, 2, 3, 4, 5
+KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME, KWS_K_MFCC_F64, KWS_K_MFCC_REFINE = 0, 1, 2, 3, 4, 5, 6
+FE_REFINE_SPAN_DEFAULT = 12.0  # KWS_FE_REFINE_SPAN_DEFAULT: log-mel span beyond which a frame is redone in float64
 FE_F32, FE_F64 = 0, 1  # KWS_FE_F32 (default: the fast float32 front end) / KWS_FE_F64 (float64 after framing, as psf)
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64 + 64 * 477  # KWS_ACT_FLOATS_PER_CLIP
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
@@ -39,6 +40,8 @@ SIGNATURES = {
     "kws_set_frontend": (C.c_int, [_c_ctx] + [C.c_int] * 7 + [C.c_float, C.c_int]),
     "kws_set_frontend_math": (C.c_int, [_c_ctx, C.c_int]),
     "kws_frontend_math": (C.c_int, [_c_ctx]),
+    "kws_set_frontend_refine": (C.c_int, [_c_ctx, C.c_float]),
+    "kws_frontend_stats": (C.c_int, [_c_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "kws_spec_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "kws_frontend_shape": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kws_mfcc_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p]),
@@ -171,6 +174,16 @@ class Context:
     def frontend_math(self) -> int:
         """FE_F32 or FE_F64: the arithmetic kws_mfcc_* actually uses for the configured geometry."""
         return int(self._lib.kws_frontend_math(self._h))
+
+    def set_frontend_refine(self, log_span: float = FE_REFINE_SPAN_DEFAULT):
+        """Frames whose log-mel values span more than ``log_span`` are recomputed in float64 (0 switches it off)."""
+        self._check(self._lib.kws_set_frontend_refine(self._h, float(log_span)), AudioProcessingError)
+
+    def frontend_stats(self):
+        """(frames through the float32 front end, frames recomputed in float64, frames the last batched call listed)."""
+        total, refined, last = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self._lib.kws_frontend_stats(self._h, C.byref(total), C.byref(refined), C.byref(last)), AudioProcessingError)
+        return int(total.value), int(refined.value), int(last.value)
 
     def frontend_shape(self):
         nf, nc = C.c_int(), C.c_int()

@@ -14,7 +14,7 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_ROOT = os.path.join(REPO, "keyword-spotting_amd")
 GOLDEN = os.path.join(REPO, "tests", "golden")
-for p in (REPO, PKG_ROOT):
+for p in (REPO, PKG_ROOT, GOLDEN):  # GOLDEN: the speech-like clip generator shared with make_golden.py
     if p not in sys.path:
         sys.path.insert(0, p)
 
