@@ -78,8 +78,9 @@ def timed_steps(step_fn, steps: int, barrier, device_sync, all_reduce_max):
     for _ in range(steps):
         step_fn()
     device_sync()
+    dt = time.perf_counter() - t0  # this rank's K steps; the clock is read BEFORE the closing barrier (a gloo round trip is not step time)
     barrier()
-    return all_reduce_max(time.perf_counter() - t0)
+    return all_reduce_max(dt)
 
 
 def pmc_traffic(kernel: str, workload: str = "ds-cnn"):
@@ -217,13 +218,17 @@ def cpu_baseline(clips: np.ndarray, blob: np.ndarray, runs: int = 5, budget_s: f
             if time.perf_counter() - t_begin > budget_s * 0.4:
                 break
             chunks = np.array_split(clips, workers * 2)
-            with ctx.Pool(workers) as pool:
+            pool = ctx.Pool(workers)
+            try:
                 pool.map(_mfcc_chunk, [c[:2] for c in chunks])  # start the workers, import numpy/scipy
                 ts = []
                 for _ in range(3):
                     t0 = time.perf_counter()
                     pool.map(_mfcc_chunk, chunks)
                     ts.append(time.perf_counter() - t0)
+            finally:  # close + join: no worker (or resource tracker child) outlives the bench command
+                pool.close()
+                pool.join()
             mfcc_rates[workers] = n / _median(ts)
     except Exception as e:  # a host that cannot spawn workers still reports the single-process figure
         pool_note = f"worker pool unavailable: {type(e).__name__}: {e}"
@@ -365,7 +370,22 @@ def dscnn_roofline(_native, launches, avg_ms, B, workload="ds-cnn"):
                 "f32 flops against the f32 MFMA peak the dtype names (a courtesy figure: this formulation could exceed it); "
                 "bf16_pipe prices the executed bf16 MFMA work against the pipe it runs on -- the engineering number",
         "bf16_pipe": {"executed_tflops": executed, "peak": PEAK_BF16_TFLOPS, "frac": executed / PEAK_BF16_TFLOPS},
+        # the two fractions side by side: `frac` (= frac_f32_algorithmic) is the contract's definition, frac_bf16_pipe is the
+        # utilisation of the matrix pipe the kernel actually runs on -- the engineering number
+        "frac_f32_algorithmic": achieved / PEAK_F32_TFLOPS, "frac_bf16_pipe": executed / PEAK_BF16_TFLOPS,
     }
+
+
+def refine_report(_native, ctx, B, steps_frames_before, steps):
+    """What the selective float64 refinement of the float32 front end did during the timed steps."""
+    total, refined, last = ctx.frontend_stats()
+    r_ms, r_n = ctx.prof_read(_native.KWS_K_MFCC_REFINE)
+    return {"kernel": _native.kernel_name(_native.KWS_K_MFCC_REFINE), "log_span_threshold": _native.FE_REFINE_SPAN_DEFAULT,
+            "frames_per_step": B * 99, "frames_recomputed_per_step": last,
+            "frames_recomputed_frac": (refined - steps_frames_before[1]) / max(total - steps_frames_before[0], 1),
+            "avg_kernel_ms": r_ms / max(r_n, 1), "launches_timed": r_n,
+            "note": "frames whose 26 log-mel values span more than the threshold are listed by the float32 kernel and recomputed in "
+                    "float64 by this launch (one per MFCC call, empty lists included)"}
 
 
 def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
@@ -385,18 +405,43 @@ def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
     ctx.prof_enable(args.prof_every)
     ctx.prof_reset()
     steps = max(10, args.config_steps // 5) if precise else args.config_steps
+    stats0 = ctx.frontend_stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     ctx.sync()
     dt = time.perf_counter() - t0
     ms, n = ctx.prof_read(kid)
+    refine = None if precise else refine_report(_native, ctx, B, stats0, steps)
     ctx.prof_enable(False)
     out = {"workload": f"configs[1]: batch={B} synthetic uniform int16 1s/16kHz clips, device-resident, MFCC(400/160/512, 26 mel, "
                        "10 cep) -> float32 [B,1,99,10]" + (", float64 front end (KWS_FE_F64)" if precise else ""),
            "value": B * steps / dt, "unit": "clips/s", "ms_per_step": dt / steps * 1e3,
            "steps": steps, "dtype": "f64" if precise else "f32",
            "roofline": hbm_roofline(_native, kid, n, ms / max(n, 1), B, "mfcc-only-f64" if precise else "mfcc-only")}
+    if refine is not None:
+        out["frames_recomputed"] = refine["frames_recomputed_per_step"]
+        out["refinement"] = refine
+        # the same call on inputs that need the refinement: the 48 diverse golden clips tiled to the batch (tones, gated
+        # bursts, chirps, four noise levels), with and without it
+        try:
+            g = np.load(GOLDEN)["clips"]
+            mix = torch.from_numpy(np.ascontiguousarray(np.tile(g, (B // len(g) + 1, 1))[:B])).to(dev)
+            res = {}
+            for tag, span in (("off", 0.0), ("on", _native.FE_REFINE_SPAN_DEFAULT)):
+                ctx.set_frontend_refine(span)
+                for _ in range(10):
+                    ctx.mfcc_i16(mix, feat)
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(max(20, steps // 2)):
+                    ctx.mfcc_i16(mix, feat)
+                ctx.sync()
+                res[tag] = (time.perf_counter() - t0) / max(20, steps // 2) * 1e3
+            out["refinement"]["golden_mix"] = {"ms_per_step_refinement_off": res["off"], "ms_per_step_refinement_on": res["on"],
+                                               "frames_recomputed_per_step": ctx.frontend_stats()[2], "frames_per_step": B * 99}
+        except Exception as e:
+            out["refinement"]["golden_mix"] = {"error": f"{type(e).__name__}: {e}"}
     if cpu_n > 0:
         from oracle import psf_mfcc as o_mfcc
 
@@ -709,6 +754,7 @@ def worker(args) -> int:
         ctx.sync()
         ctx.prof_enable(args.prof_every)
         ctx.prof_reset()
+        stats0 = ctx.frontend_stats()
 
     t_local0 = time.perf_counter()
     elapsed = timed_steps(step, args.steps, barrier, sync, reduce_max)
@@ -803,6 +849,8 @@ def worker(args) -> int:
                                 "f32_frac": (B / (mfcc_ms * 1e-3) * MFCC_FLOP_PER_CLIP / (PEAK_F32_TFLOPS * 1e12)) if mfcc_ms > 0 else 0.0},
                 **multi,
             }
+            if args.frontend_math != "f64":
+                out["frontend_refinement"] = refine_report(_native, ctx, B, stats0, args.steps)
             lab = labels.cpu().numpy()
             out["labels_seen"] = {"n_classes": int(len(np.unique(lab))), "logit_std_across_clips": float(logits.std(dim=0).mean().item())}
             if golden is not None and not args.no_parity:  # the 48 diverse golden clips against the imported reference model's logits (data file)

@@ -574,7 +574,9 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 // states for a 16-pass MFMA).  The wait is spelled out here; the +v ties pin it after the last MFMA.
                 // (Round 1's `valid ? relu(x) : 0` happened to put an exec-mask branch in between; a branch-free select
                 // read stale accumulators: nondeterministic sums.)
+#ifndef KWS_X_NO_MFMA_EPILOGUE_NOP  // (the switch exists for tests/test_isa_hazards.py: without the wait the lint must fail)
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
+#endif
                 if constexpr (N < 4) {
                     if (valid) {
 #pragma unroll

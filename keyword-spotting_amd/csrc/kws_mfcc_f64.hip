@@ -175,8 +175,12 @@ __global__ __launch_bounds__(F64_MAX_WAVES * 64) void kws_mfcc_f64_kernel(Fronte
 // vowel) cost one transform per two frames.  The last workgroup to finish folds the number of rows rewritten (ctr[1],
 // counted by the float32 kernel) into the running total (ctr[2..3], 64 bits), keeps it as "last call" (ctr[4]) and clears
 // the counters for the next launch.
+#ifndef KWS_X_REFINE_WAVES
+#define KWS_X_REFINE_WAVES 8
+#endif
+constexpr int REFINE_WAVES = KWS_X_REFINE_WAVES;  // wavefronts per workgroup of the refinement kernel
 template <typename T>
-__global__ __launch_bounds__(F64_MAX_WAVES * 64) void kws_mfcc_refine_kernel(FrontendParams p, FrontendTables t, const T* __restrict__ wav,
+__global__ __launch_bounds__(REFINE_WAVES * 64) void kws_mfcc_refine_kernel(FrontendParams p, FrontendTables t, const T* __restrict__ wav,
                                                                          float* __restrict__ out, RefineList rl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem64[];
     constexpr int NCT = 512;
@@ -311,19 +315,21 @@ hipError_t launch_mfcc_f64_t(hipStream_t s, const FrontendParams& p, const Front
     return hipGetLastError();
 }
 
-// Refinement launch: a fixed grid -- the three four-wavefront workgroups a CU's LDS holds, on 256 CUs.
+// Refinement launch: a fixed grid of one eight-wavefront workgroup per CU (the kernel's ~200 registers allow two
+// wavefronts per SIMD).  Workgroups cost time even when they leave at once: with four-wavefront workgroups, 256 / 512 /
+// 768 of them took 14.9 / 18.3 / 22.8 us on a batch with 583 listed frames (same box, same call).
 #ifndef KWS_X_REFINE_GRID
-#define KWS_X_REFINE_GRID (256 * 3)
+#define KWS_X_REFINE_GRID 256
 #endif
 constexpr int REFINE_GRID = KWS_X_REFINE_GRID;
 template <typename T>
 hipError_t launch_mfcc_refine_t(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const T* d_wav, float* d_out,
                                 const RefineList& rl) {
-    const size_t lds = f64_layout(512, true, true, p.nfilt, p.numcep, F64_MAX_WAVES).total;
+    const size_t lds = f64_layout(512, true, true, p.nfilt, p.numcep, REFINE_WAVES).total;
     auto kernel = kws_mfcc_refine_kernel<T>;
     hipError_t e = raise_lds_limit(kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(REFINE_GRID), dim3(F64_MAX_WAVES * 64), lds, s, p, t, d_wav, d_out, rl);
+    hipLaunchKernelGGL(kernel, dim3(REFINE_GRID), dim3(REFINE_WAVES * 64), lds, s, p, t, d_wav, d_out, rl);
     return hipGetLastError();
 }
 

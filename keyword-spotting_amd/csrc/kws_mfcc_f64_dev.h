@@ -295,8 +295,13 @@ __device__ __forceinline__ void f64_tail(const FrontendParams& p, const F64Tabs&
         auto other_half = [](double v) {
             const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
             unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32), lo2 = lo, hi2 = hi;
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));  // lo: lanes >= 32 get lo2 of lanes < 32; lo2: lanes < 32 get lo of lanes >= 32
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(hi), "+v"(hi2));
+            // lo: lanes >= 32 get lo2 of lanes < 32; lo2: lanes < 32 get lo of lanes >= 32.  One block, led by two wait
+            // states: a VALU write followed by a permlane swap of the same register needs them (the compiler inserts
+            // `s_nop 1` for its own swaps but does not look into asm -- found by tools/isa_hazard_lint.py, rule R2).
+            asm volatile("s_nop 1\n\t"
+                         "v_permlane32_swap_b32 %0, %1\n\t"
+                         "v_permlane32_swap_b32 %2, %3"
+                         : "+v"(lo), "+v"(lo2), "+v"(hi), "+v"(hi2));
             const bool upper = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32) != 0;
             return __builtin_bit_cast(double, ((unsigned long long)(upper ? hi : hi2) << 32) | (upper ? lo : lo2));
         };

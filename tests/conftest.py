@@ -58,6 +58,13 @@ def e2e_golden():
 
 
 @pytest.fixture(scope="session")
+def stress_golden():
+    """16 speech-like clips + three weight tags (he, he5: 5x classifier gain, raw: conv1 not pre-divided by the MFCC maps' RMS)
+    -> logits / labels of the imported reference model for the 48 diverse clips of e2e_golden followed by the 16 (make_golden.py)."""
+    return np.load(os.path.join(GOLDEN, "stress_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def dsblock_golden():
     """DepthwiseSeparableConvBlock on its own: inputs, parameters and the imported reference module's outputs."""
     return np.load(os.path.join(GOLDEN, "dsblock_golden.npz"))

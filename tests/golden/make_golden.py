@@ -11,6 +11,11 @@ Writes (data only -- inputs and expected outputs, no reference source):
                                     DepthwiseSeparableConv logits, per-layer probes
   tests/golden/dsblock_golden.npz   DepthwiseSeparableConvBlock on its own: four shapes -> reference outputs
   tests/golden/multichannel_golden.npz  DepthwiseSeparableConv(input_channels=3) on ten 3-channel maps -> reference logits
+  tests/golden/stress_golden.npz    16 speech-like clips (tests/golden/speechlike.py: glottal pulse trains through formant
+                                    resonators, pauses of exact zeros / +-1 LSB dither, -6 .. -50 dBFS) and three weight
+                                    tags -- the 'he' weights, the same with a 5x classifier gain, and weights whose conv1
+                                    is NOT pre-divided by the MFCC maps' RMS (activations and logits ~15x larger) ->
+                                    reference logits / labels for these 16 + the 48 diverse clips of e2e_golden.npz
   tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
                                     reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
                                     AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
@@ -274,6 +279,57 @@ def e2e_golden():
     print("e2e_golden.npz written; labels:", labels.tolist())
 
 
+def stress_golden():
+    """Inputs and weights that can break the 1e-4 logit bound: speech-like clips -- a few strong
+    harmonics over a floor 60-90 dB down inside one frame, onsets next to digital silence, levels down to -50 dBFS -- and
+    weights with larger gains than the 'he' tag.  Logits and labels from the imported reference model on the oracle's MFCC."""
+    sys.path.insert(0, HERE)
+    import speechlike
+
+    sp_clips, sp_names = speechlike.speechlike_set(16, 400)
+    div_clips, _ = diverse_clips()
+    clips = np.concatenate([div_clips, sp_clips])
+    # how hard these clips are for a float32 front end: frames whose mel bands span more than 50 dB (11.5 in log power)
+    over50 = []
+    for c in sp_clips:
+        feat, _ = o_mfcc.fbank(o_mfcc.fix_length(o_mfcc.pcm16_to_float(c), N))
+        lm = np.log(feat)
+        over50.append(((lm.max(1) - lm.min(1)) > 11.5).mean())
+    print(f"speech-like clips: {100 * np.mean(over50):.1f} % of frames span more than 50 dB (per clip: "
+          + " ".join(f"{100 * v:.0f}" for v in over50) + ")")
+    x = torch.from_numpy(o_mfcc.collate_pcm16(clips))
+    g = np.load(os.path.join(HERE, "e2e_golden.npz"))
+    he = {}
+    off = 0
+    for k, shp in o_dscnn.state_shapes(12).items():
+        n = int(np.prod(shp))
+        he[k] = torch.from_numpy(g["he.blob"][off:off + n].reshape(shp).copy())
+        off += n
+    he5 = {k: v.clone() for k, v in he.items()}
+    he5["fc.weight"] = (he["fc.weight"] * 5.0).float()
+    he5["fc.bias"] = (he["fc.bias"] * 5.0).float()
+    raw = he_state(seed=3, in_scale=1.0)                      # conv1 NOT pre-divided by the MFCC maps' RMS
+    l0, _, _ = ref_forward_with_layers(raw, x)
+    raw["fc.bias"] = (raw["fc.bias"] - l0.mean(0)).float()      # classes balanced over the clip set, as in the 'he' tag
+    save = {"speech_clips": sp_clips, "speech_names": np.array(sp_names), "speech_frac_frames_over_50dB": np.array(over50)}
+    for tag, st in (("he", he), ("he5", he5), ("raw", raw)):
+        logits, labels, _ = ref_forward_with_layers(st, x)
+        o_logits = o_dscnn.forward(st, x)
+        np.testing.assert_allclose(o_logits.numpy(), logits.numpy(), rtol=0, atol=2e-6 * float(logits.abs().max()))
+        assert torch.equal(o_dscnn.predict(o_logits), labels)
+        top2 = torch.topk(logits, 2, dim=1).values
+        print(f"{tag}: {len(set(labels.tolist()))} classes over {len(clips)} clips, logit std across clips {float(logits.std(0).mean()):.2f}, "
+              f"|logit| max {float(logits.abs().max()):.1f}, min top-2 margin {float((top2[:, 0] - top2[:, 1]).min()):.2e}, "
+              f"oracle vs reference {float((o_logits - logits).abs().max()):.1e}")
+        save[f"{tag}.blob"] = o_dscnn.flatten_state(st)
+        save[f"{tag}.logits"] = logits.numpy()
+        save[f"{tag}.label"] = labels.numpy()
+    if "he" in save:
+        np.testing.assert_array_equal(save["he.logits"][:48], g["he.logits"][8:])  # the same model on the same 48 clips
+    np.savez_compressed(os.path.join(HERE, "stress_golden.npz"), **save)
+    print("stress_golden.npz written")
+
+
 def dsblock_golden():
     """DepthwiseSeparableConvBlock (kws/libs/models.py:75-119) on its own, imported and run: three shapes incl. a
     non-default kernel size / stride / padding and channel counts that are not multiples of the kernel's tiles."""
@@ -335,8 +391,8 @@ def multichannel_golden():
 
 
 if __name__ == "__main__":
-    sigproc_golden()
-    dscnn_golden()
-    e2e_golden()
-    dsblock_golden()
-    multichannel_golden()
+    only = set(sys.argv[1:])  # e.g. `make_golden.py stress` regenerates one file; no argument = all
+    for name, fn in (("sigproc", sigproc_golden), ("dscnn", dscnn_golden), ("e2e", e2e_golden), ("stress", stress_golden),
+                     ("dsblock", dsblock_golden), ("multichannel", multichannel_golden)):
+        if not only or name in only:
+            fn()

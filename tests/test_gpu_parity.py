@@ -528,6 +528,33 @@ def test_infer_golden_diverse_clips(ctx, dev, e2e_golden):
     assert np.abs(logits[0] - logits[4]).max() > 0.5
 
 
+@pytest.mark.parametrize("tag", ["he", "he5", "raw"])
+def test_infer_stress_clips_and_weight_tags(native, dev, e2e_golden, stress_golden, tag):
+    """Inputs and weights chosen to break the logit bound: 16 speech-like clips (harmonics over a floor 60-90 dB down, pauses
+    of exact zeros and of +-1 LSB dither, -6 .. -50 dBFS) next to the 48 diverse clips, under the 'he' weights, the same
+    with a 5x classifier gain (logits up to 40) and weights whose conv1 is NOT pre-divided by the MFCC maps' RMS (logits up
+    to 200).  Expected values: the imported reference model on the oracle's MFCC (make_golden.py stress)."""
+    clips = np.concatenate([e2e_golden["clips"], stress_golden["speech_clips"]])
+    want, want_label = stress_golden[f"{tag}.logits"], stress_golden[f"{tag}.label"]
+    c = make_ctx(native)
+    try:
+        c.load_dscnn(stress_golden[f"{tag}.blob"], 12)
+        logits, labels = gpu_infer(c, dev, clips)
+    finally:
+        c.close()
+    err = np.abs(logits - want).max(axis=1)
+    scale = float(np.abs(want).max())
+    # 1e-4 absolute (north_star) while the logits are O(10); float32 itself resolves 6e-8 of the largest activation, and two
+    # correct float32 implementations of this network differ by ~2e-6 of the largest logit (the generator's own
+    # oracle-vs-reference gate), so beyond |logit| ~ 50 the bound is that float32 floor
+    gate = max(TOL, 2e-6 * scale)
+    names = [str(n) for n in e2e_golden["names"]] + [str(n) for n in stress_golden["speech_names"]]
+    worst = int(err.argmax())
+    assert err.max() <= gate, f"{tag}: clip {names[worst]} logits off by {err.max():.2e} (gate {gate:.1e}, |logit| max {scale:.1f})"
+    assert np.array_equal(labels, want_label), [names[i] for i in np.nonzero(labels != want_label)[0]]
+    assert len(set(want_label.tolist())) >= 6
+
+
 @pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
 def test_infer_matches_oracle(ctx, dev, e2e_golden, kind, seed):
     blob = e2e_golden["he.blob"]

@@ -28,7 +28,7 @@ wav = torch.from_numpy(clips).to(dev)
 out = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
 for _ in range(150): ctx.mfcc_i16(wav, out)  # clocks settle after ~30 launches (bench.py --spinup)
 torch.cuda.synchronize()
-res = {0.0: [], _native.FE_REFINE_SPAN_DEFAULT: []}
+res = {0.0: [], 1e9: [], _native.FE_REFINE_SPAN_DEFAULT: []}  # off / flags computed but nothing listed (an empty refinement launch) / on
 for rnd in range(3):
     for span in res:
         ctx.set_frontend_refine(span)
@@ -39,15 +39,17 @@ for rnd in range(3):
         for _ in range(100): ctx.mfcc_i16(wav, out)
         t1.record(); torch.cuda.synchronize()
         res[span].append(t0.elapsed_time(t1) / 100)
-ctx.set_frontend_refine(_native.FE_REFINE_SPAN_DEFAULT)
-ctx.prof_reset(); ctx.prof_enable(4)
-for _ in range(100): ctx.mfcc_i16(wav, out)
-ms_f32, n_f32 = ctx.prof_read(_native.KWS_K_MFCC)
-ms_ref, n_ref = ctx.prof_read(_native.KWS_K_MFCC_REFINE)
-ctx.prof_enable(0)
+kern = {}
+for span in (0.0, 1e9, _native.FE_REFINE_SPAN_DEFAULT):  # kernel-only times (HIP events on the stream, every 4th launch)
+    ctx.set_frontend_refine(span)
+    ctx.prof_reset(); ctx.prof_enable(4)
+    for _ in range(200): ctx.mfcc_i16(wav, out)
+    kern[span] = (ctx.prof_read(_native.KWS_K_MFCC), ctx.prof_read(_native.KWS_K_MFCC_REFINE))
+    ctx.prof_enable(0)
+(ms_f32, n_f32), (ms_ref, n_ref) = kern[_native.FE_REFINE_SPAN_DEFAULT]
 total, refined, last = ctx.frontend_stats()
 name = os.environ.get('KWS_HIP_LIB', 'default')
-print(f"{name:40s} {kind}: mfcc call {min(res[0.0]):.4f} ms without refinement, {min(res[_native.FE_REFINE_SPAN_DEFAULT]):.4f} ms with "
-      f"(rounds {['%.4f' % v for v in res[0.0]]} / {['%.4f' % v for v in res[_native.FE_REFINE_SPAN_DEFAULT]]}); "
+print(f"{os.path.basename(name):24s} {kind}: mfcc call {min(res[0.0]):.4f} ms without refinement, {min(res[1e9]):.4f} with an empty list, {min(res[_native.FE_REFINE_SPAN_DEFAULT]):.4f} ms with; "
+      f"float32 kernel {kern[0.0][0][0] / max(kern[0.0][0][1], 1):.4f} ms without the flag, {kern[1e9][0][0] / max(kern[1e9][0][1], 1):.4f} with, empty refinement launch {kern[1e9][1][0] / max(kern[1e9][1][1], 1):.4f} ms; "
       f"float32 kernel {ms_f32 / max(n_f32, 1):.4f} ms, refinement launch {ms_ref / max(n_ref, 1):.4f} ms, "
       f"{last} of {B * 99} frames refined per call ({100.0 * last / (B * 99):.3f} %)  checksum {float(out.double().sum()):.6f}")
