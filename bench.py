@@ -442,6 +442,9 @@ def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
                                                "frames_recomputed_per_step": ctx.frontend_stats()[2], "frames_per_step": B * 99}
         except Exception as e:
             out["refinement"]["golden_mix"] = {"error": f"{type(e).__name__}: {e}"}
+        ctx.set_frontend_refine(_native.FE_REFINE_SPAN_DEFAULT)
+        step()  # `feat` holds the step's own clips again for the parity figure below
+        ctx.sync()
     if cpu_n > 0:
         from oracle import psf_mfcc as o_mfcc
 

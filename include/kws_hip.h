@@ -142,6 +142,19 @@ int kws_load_dscnn_ex(kws_ctx* ctx, const float* blob, size_t n_floats, int num_
  * kws/libs/training.py:371) or NULL.  Replaces DepthwiseSeparableConv.forward (models.py:160-183). */
 int kws_forward_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
 
+/* The same forward for a feature map of ANY size: d_feat float32 [B, input_channels, T, F] -- DepthwiseSeparableConv.forward
+ * takes any [B,C,T,F] (models.py:160-183; the global average pool is adaptive) and AudioConfig.clip_duration_ms /
+ * num_cepstral_coeffs change T and F (audio_processor.py:37-46).  T x F == 99 x 10 runs the fused LDS-resident kernel;
+ * any other map runs composed through HBM: conv1 (10x10, stride 2, padding 2) -> four depthwise-separable blocks (each
+ * adds its relu(bias) ring) -> global average pool + fc + argmax.  Needs T >= 6, F >= 6 and (T+4)*(F+4) <= 40960.
+ * kws_infer_i16 / kws_infer_f32 / kws_infer_host_i16 follow kws_frontend_shape through this entry. */
+int kws_forward_map_f32(kws_ctx* ctx, const float* d_feat, int B, int T, int F, float* d_logits, int32_t* d_label);
+/* Parity aid for the composed path: also stores every stage's output to d_layers, stage after stage, each stage as
+ * [B][64][H][W] -- conv1 (H1 x W1, H1 = (T-6)/2+1, W1 = (F-6)/2+1), then blocks 1..4 WITH their rings ((H1+2k) x (W1+2k)).
+ * A 99 x 10 map takes the composed path here too (an independent check of the fused kernel). */
+int kws_forward_map_debug_f32(kws_ctx* ctx, const float* d_feat, int B, int T, int F, float* d_logits, int32_t* d_label,
+                              float* d_layers);
+
 /* One depthwise-separable block on an arbitrary map -- replaces DepthwiseSeparableConvBlock.forward
  * (kws/libs/models.py:108-119) used on its own: depthwise Conv2d(C_in, C_in, kernel_size, stride, padding, groups=C_in)
  * + bias, then pointwise Conv2d(C_in, C_out, 1, padding=padding) + bias, then ReLU.  d_x float32 [B,C_in,H,W]; d_dw_w

@@ -473,13 +473,16 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
                  o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64,
                  o_split = (o_fcb + num_classes + 3) & ~(size_t)3, o_c1s = o_split + 4 * 2 * 4 * 3 * 64 * 4,
-                 o_c1g = o_c1s + 2 * 7 * 3 * 64 * 4, total = o_c1g + (input_channels > 1 ? c1_floats : 0);
+                 o_c1g = o_c1s + 2 * 7 * 3 * 64 * 4, o_raw = o_c1g + c1_floats, total = o_raw + n_floats;
     std::vector<float> h(total, 0.f);
     const float* src = blob;
-    if (input_channels > 1)  // conv1.weight [64][C][10][10] -> [ci][tap][cout]
+    memcpy(&h[o_raw], blob, n_floats * sizeof(float));  // torch layouts, for the composed any-map path (kws_forward_map_f32)
+    // conv1.weight [64][C][10][10] -> [ci][tap][cout] (kws_conv1_general_kernel for C > 1, kws_conv1_any_kernel for any map)
+    {
         for (int co = 0; co < 64; ++co)
             for (int ci = 0; ci < input_channels; ++ci)
                 for (int k = 0; k < 100; ++k) h[o_c1g + ((size_t)ci * 100 + k) * 64 + co] = src[((size_t)co * input_channels + ci) * 100 + k];
+    }
     for (int co = 0; co < 64 && input_channels == 1; ++co)  // conv1.weight [64][1][10][10] -> [k][cout]
         for (int k = 0; k < 100; ++k) h[o_c1w + (size_t)k * 64 + co] = src[co * 100 + k];
     if (input_channels == 1) {
@@ -566,7 +569,8 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
     c->mw.in_channels = input_channels;
-    c->mw.c1_general = input_channels > 1 ? d + o_c1g : nullptr;
+    c->mw.c1_general = d + o_c1g;
+    c->mw.raw = d + o_raw;
     c->model_ready = true;
     return KWS_OK;
 }
@@ -710,6 +714,68 @@ int kws_forward_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int
     return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, c ? c->pw_math : 0, "kws_forward_f32");
 }
 
+// DepthwiseSeparableConv.forward on a feature map of any size (models.py:160-183): T x F == 99 x 10 takes the fused
+// LDS-resident kernel, anything else runs composed through HBM -- conv1 -> four depthwise-separable blocks (the standalone
+// block kernels, each adding its relu(bias) ring) -> global average pool + fc + argmax.
+static int forward_map_impl(kws_ctx* c, const float* d_feat, int B, int T, int F, float* d_logits, int32_t* d_label, float* d_layers,
+                            const char* fn) {
+    int rc = check_batch(c, d_feat, B, fn);
+    if (rc) return rc;
+    if (!d_logits) return fail(c, KWS_EINVAL, std::string(fn) + ": d_logits is NULL");
+    if (!c->model_ready) return fail(c, KWS_ESTATE, std::string(fn) + ": no model loaded (kws_load_dscnn)");
+    if (T == IN_T && F == IN_F && !d_layers) return forward_impl(c, d_feat, B, d_logits, d_label, nullptr, c->pw_math, fn);
+    if (T < 6 || F < 6) return fail(c, KWS_EINVAL, std::string(fn) + ": the 10 x 10 first convolution (padding 2) needs T >= 6 and F >= 6");
+    if ((size_t)(T + 4) * (F + 4) * sizeof(float) > 160 * 1024)
+        return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": the padded feature map must fit 160 KB of LDS ((T + 4) * (F + 4) <= 40960)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int H1 = (T - 6) / 2 + 1, W1 = (F - 6) / 2 + 1, Cin = c->mw.in_channels, C = c->mw.num_classes;
+    const size_t per_clip_max = (size_t)CH * (H1 + 8) * (W1 + 8);   // block 4's output, ring included
+    const size_t dw_max = (size_t)CH * (H1 + 6) * (W1 + 6);        // block 4's depthwise output
+    const int chunk = B < 16384 ? B : 16384;                        // grid.z of the pointwise kernel, and a bounded workspace
+    rc = grow_conv_ws(c, (size_t)chunk * (2 * per_clip_max + dw_max), fn);
+    if (rc) return rc;
+    float* bufs[2] = {c->d_conv_ws, c->d_conv_ws + (size_t)chunk * per_clip_max};
+    float* dw_ws = c->d_conv_ws + 2 * (size_t)chunk * per_clip_max;
+    const float* raw = c->mw.raw + (size_t)6400 * Cin + 64;        // first block's parameters in state_dict order
+    size_t layer_off = 0;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = B - b0 < chunk ? B - b0 : chunk;
+        HIP_TRY(c, launch_conv1_any(c->stream, d_feat + (size_t)b0 * Cin * T * F, nb, Cin, T, F, c->mw.c1_general, c->mw.c1_b, bufs[0]));
+        int H = H1, W = W1, cur = 0;
+        size_t lo = 0;
+        auto dump = [&](const float* src, size_t per_clip) -> hipError_t {  // diagnostics: stage outputs, stage-major, batch inside
+            if (!d_layers) return hipSuccess;
+            hipError_t e = hipMemcpyAsync(d_layers + lo * B + (size_t)b0 * per_clip, src, sizeof(float) * per_clip * nb, hipMemcpyDeviceToDevice, c->stream);
+            lo += per_clip;
+            return e;
+        };
+        HIP_TRY(c, dump(bufs[0], (size_t)CH * H * W));
+        for (int blk = 0; blk < N_BLOCKS; ++blk) {
+            const float* prm = raw + (size_t)blk * (576 + 64 + 4096 + 64);
+            HIP_TRY(c, launch_dsblock(c->stream, bufs[cur], nb, CH, H, W, prm, prm + 576, prm + 640, prm + 640 + 4096, CH, 3, 1, 1, dw_ws,
+                                      bufs[cur ^ 1]));
+            cur ^= 1;
+            H += 2;
+            W += 2;
+            HIP_TRY(c, dump(bufs[cur], (size_t)CH * H * W));
+        }
+        HIP_TRY(c, launch_pool_fc(c->stream, bufs[cur], nb, H * W, c->mw.fc_w, c->mw.fc_b, C, d_logits + (size_t)b0 * C,
+                                  d_label ? d_label + b0 : nullptr));
+        layer_off = lo;
+    }
+    (void)layer_off;
+    return KWS_OK;
+}
+
+int kws_forward_map_f32(kws_ctx* c, const float* d_feat, int B, int T, int F, float* d_logits, int32_t* d_label) {
+    return forward_map_impl(c, d_feat, B, T, F, d_logits, d_label, nullptr, "kws_forward_map_f32");
+}
+
+int kws_forward_map_debug_f32(kws_ctx* c, const float* d_feat, int B, int T, int F, float* d_logits, int32_t* d_label, float* d_layers) {
+    if (c && !d_layers) return fail(c, KWS_EINVAL, "kws_forward_map_debug_f32: d_layers is NULL");
+    return forward_map_impl(c, d_feat, B, T, F, d_logits, d_label, d_layers, "kws_forward_map_debug_f32");
+}
+
 int kws_set_pointwise_math(kws_ctx* c, int math) {
     if (!c) return KWS_EINVAL;
     if (math != KWS_PW_F32 && math != KWS_PW_SPLIT_BF16)
@@ -742,13 +808,12 @@ int kws_infer_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_logits, int3
     if (rc) return rc;
     if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_i16: front end or model not configured");
     if (c->mw.in_channels != 1) return fail(c, KWS_EUNSUPPORTED, "kws_infer_i16: the MFCC front end yields one channel; the model was loaded with more");
-    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
-        return fail(c, KWS_EUNSUPPORTED, "kws_infer_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
     rc = kws_reserve(c, B);
     if (rc) return rc;
     rc = kws_mfcc_i16(c, d_wav, B, c->d_feat_ws);
     if (rc) return rc;
-    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, c->pw_math, "kws_infer_i16");
+    // 99 x 10 (the reference geometry): the fused kernel; any other map kws_frontend_shape yields: the composed path
+    return forward_map_impl(c, c->d_feat_ws, B, c->fp.num_frames, c->fp.numcep, d_logits, d_label, nullptr, "kws_infer_i16");
 }
 
 int kws_infer_f32(kws_ctx* c, const float* d_wav, int B, float* d_logits, int32_t* d_label) {
@@ -756,13 +821,11 @@ int kws_infer_f32(kws_ctx* c, const float* d_wav, int B, float* d_logits, int32_
     if (rc) return rc;
     if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_f32: front end or model not configured");
     if (c->mw.in_channels != 1) return fail(c, KWS_EUNSUPPORTED, "kws_infer_f32: the MFCC front end yields one channel; the model was loaded with more");
-    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
-        return fail(c, KWS_EUNSUPPORTED, "kws_infer_f32: the DS-CNN kernel is built for a 99 x 10 feature map");
     rc = kws_reserve(c, B);
     if (rc) return rc;
     rc = kws_mfcc_f32(c, d_wav, B, c->d_feat_ws);
     if (rc) return rc;
-    return forward_impl(c, c->d_feat_ws, B, d_logits, d_label, nullptr, c->pw_math, "kws_infer_f32");
+    return forward_map_impl(c, c->d_feat_ws, B, c->fp.num_frames, c->fp.numcep, d_logits, d_label, nullptr, "kws_infer_f32");
 }
 
 // ---- streaming ------------------------------------------------------------------------------------

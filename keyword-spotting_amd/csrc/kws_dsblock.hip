@@ -110,7 +110,107 @@ __global__ __launch_bounds__(256) void kws_dsblock_pointwise_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The rest of DepthwiseSeparableConv.forward for feature maps other than 99 x 10 (reference kws/libs/models.py:160-183 takes
+// any [B, C, T, F]: AudioConfig.clip_duration_ms / num_cepstral_coeffs change T and F, audio_processor.py:37-46).  The
+// fused LDS-resident kernel is built for the reference geometry; any other map runs composed and HBM-resident:
+// conv1 (below) -> 4 x launch_dsblock -> pool + fc (below).
+//
+// conv1: Conv2d(C_in, 64, 10, stride 2, padding 2) + bias + ReLU (models.py:135,170).  One workgroup per (clip, tile of 64
+// output positions); thread (co = tid & 63, pg = tid >> 6) owns output channel co at positions pg, pg + 4, ... of the tile.
+// Per input channel the zero-padded plane goes through LDS (every lane of a wavefront reads the same address: a
+// broadcast) and the 100 taps come from the [ci][tap][co] weight image (coalesced).
+constexpr int C1A_POS = 64, C1A_PER = C1A_POS / 4;
+__global__ __launch_bounds__(256) void kws_conv1_any_kernel(const float* __restrict__ x, int C_in, int T, int F, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, int Ho, int Wo, float* __restrict__ out) {
+    extern __shared__ float plane[];  // (T + 4) x (F + 4)
+    const int tid = threadIdx.x, co = tid & 63, pg = tid >> 6;
+    const int Hp = T + 4, Wp = F + 4, P = Ho * Wo, p0 = blockIdx.x * C1A_POS;
+    float acc[C1A_PER];
+    int base[C1A_PER];  // plane offset of the position's top-left tap (position p: rows 2*(p / Wo) .., columns 2*(p % Wo) ..)
+#pragma unroll
+    for (int k = 0; k < C1A_PER; ++k) {
+        acc[k] = 0.f;
+        const int p = min(p0 + pg + 4 * k, P - 1);
+        base[k] = 2 * (p / Wo) * Wp + 2 * (p % Wo);
+    }
+    const float* xc = x + (size_t)blockIdx.y * C_in * T * F;
+    for (int ci = 0; ci < C_in; ++ci) {
+        __syncthreads();
+        for (int i = tid; i < Hp * Wp; i += 256) {
+            const int r = i / Wp - 2, c = i % Wp - 2;
+            plane[i] = ((unsigned)r < (unsigned)T && (unsigned)c < (unsigned)F) ? xc[(size_t)ci * T * F + r * F + c] : 0.f;
+        }
+        __syncthreads();
+        const float* wc = wt + (size_t)ci * 100 * 64 + co;
+        for (int tap = 0; tap < 100; ++tap) {
+            const float wv = wc[(size_t)tap * 64];
+            const int off = (tap / 10) * Wp + tap % 10;
+#pragma unroll
+            for (int k = 0; k < C1A_PER; ++k) acc[k] = fmaf(wv, plane[base[k] + off], acc[k]);
+        }
+    }
+    float* o = out + ((size_t)blockIdx.y * 64 + co) * P;
+    const float bv = bias[co];
+#pragma unroll
+    for (int k = 0; k < C1A_PER; ++k) {
+        const int p = p0 + pg + 4 * k;
+        if (p < P) o[p] = relu(acc[k] + bv);
+    }
+}
+
+// F.adaptive_avg_pool2d(x, (1, 1)) + view + fc (models.py:179-181) + argmax, first maximum wins (training.py:371).
+// x: [B][64][HW] (the last block's output, ring included).  One workgroup per clip: four partial sums per channel, fc and
+// argmax on wavefront 0.
+__global__ __launch_bounds__(256) void kws_pool_fc_kernel(const float* __restrict__ x, int HW, const float* __restrict__ fc_w,
+                                                          const float* __restrict__ fc_b, int C, float* __restrict__ logits,
+                                                          int32_t* __restrict__ label) {
+    __shared__ float part[4][64];
+    __shared__ float pooled[64];
+    __shared__ float lg[MAX_CLASSES];
+    const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+    const float* xp = x + ((size_t)blockIdx.x * 64 + c) * HW;
+    float s = 0.f;
+    for (int i = q; i < HW; i += 4) s += xp[i];
+    part[q][c] = s;
+    __syncthreads();
+    if (tid < 64) pooled[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) * (1.0f / (float)HW);
+    __syncthreads();
+    if (tid < C) {
+        float acc = fc_b[tid];
+        for (int k = 0; k < 64; ++k) acc = fmaf(fc_w[tid * 64 + k], pooled[k], acc);
+        logits[(size_t)blockIdx.x * C + tid] = acc;
+        lg[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0 && label) {
+        int best = 0;
+        for (int k = 1; k < C; ++k)
+            if (lg[k] > lg[best]) best = k;  // strict: the first maximum wins
+        label[blockIdx.x] = best;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_conv1_any(hipStream_t s, const float* d_x, int B, int C_in, int T, int F, const float* d_wt, const float* d_bias,
+                            float* d_out) {
+    const int Ho = (T + 4 - 10) / 2 + 1, Wo = (F + 4 - 10) / 2 + 1;
+    const size_t lds = sizeof(float) * (size_t)(T + 4) * (F + 4);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kws_conv1_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kws_conv1_any_kernel, dim3((Ho * Wo + C1A_POS - 1) / C1A_POS, B), dim3(256), lds, s, d_x, C_in, T, F, d_wt, d_bias,
+                       Ho, Wo, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_fc(hipStream_t s, const float* d_x, int B, int HW, const float* d_fc_w, const float* d_fc_b, int C,
+                          float* d_logits, int32_t* d_label) {
+    hipLaunchKernelGGL(kws_pool_fc_kernel, dim3(B), dim3(256), 0, s, d_x, HW, d_fc_w, d_fc_b, C, d_logits, d_label);
+    return hipGetLastError();
+}
 
 hipError_t launch_dsblock(hipStream_t s, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w, const float* d_dw_b,
                           const float* d_pw_w, const float* d_pw_b, int C_out, int k, int stride, int pad, float* d_ws,

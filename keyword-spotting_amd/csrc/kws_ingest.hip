@@ -235,8 +235,6 @@ int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits,
     if (!h_wav || !h_logits) return fail(c, KWS_EINVAL, "kws_infer_host_i16: h_wav and h_logits must not be NULL");
     if (B <= 0) return fail(c, KWS_EINVAL, "kws_infer_host_i16: B must be positive");
     if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_host_i16: front end or model not configured");
-    if (c->fp.num_frames != IN_T || c->fp.numcep != IN_F)
-        return fail(c, KWS_EUNSUPPORTED, "kws_infer_host_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ingest_prepare(c);
     if (rc) return rc;

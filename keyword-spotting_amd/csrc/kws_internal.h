@@ -148,7 +148,8 @@ struct DscnnWeights {
     const float* fc_b;     // [C]
     int num_classes;
     int in_channels;           // 1: the fused kernel computes conv1 itself; > 1: kws_conv1_general_kernel + the PRECONV entry
-    const float* c1_general;   // [ci][100][64]  conv1 weights of a multi-channel model (in_channels > 1), else NULL
+    const float* c1_general;   // [ci][100][64]  conv1 weights as [ci][tap][cout] (multi-channel models and the composed any-map path)
+    const float* raw;          // the state_dict blob as loaded (torch layouts): the composed path's depthwise / pointwise operands
 };
 
 hipError_t dscnn_init_device();
@@ -196,6 +197,13 @@ hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const fl
 hipError_t launch_dsblock(hipStream_t s, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w, const float* d_dw_b,
                           const float* d_pw_w, const float* d_pw_b, int C_out, int k, int stride, int pad, float* d_ws,
                           float* d_out);
+
+// DS-CNN on a feature map other than 99 x 10 (composed, HBM-resident): conv1 for any [B][C_in][T][F] (d_wt: [ci][tap][co]) and
+// global average pool + fc + argmax over [B][64][HW].
+hipError_t launch_conv1_any(hipStream_t s, const float* d_x, int B, int C_in, int T, int F, const float* d_wt, const float* d_bias,
+                            float* d_out);
+hipError_t launch_pool_fc(hipStream_t s, const float* d_x, int B, int HW, const float* d_fc_w, const float* d_fc_b, int C,
+                          float* d_logits, int32_t* d_label);
 
 hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, float* d_prob);
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,

@@ -49,6 +49,8 @@ SIGNATURES = {
     "kws_load_dscnn": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
     "kws_load_dscnn_ex": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int]),
     "kws_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
+    "kws_forward_map_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p]),
+    "kws_forward_map_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _f32p]),
     "kws_infer_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_dsblock_forward_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _f32p]),
@@ -211,6 +213,16 @@ class Context:
             self._lib.kws_forward_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits), _ptr(label) if label is not None else None),
             ModelError,
         )
+
+    def forward_map_f32(self, feat, logits, label=None, layers=None):
+        """``feat`` float32 [B, C, T, F] of any size (99 x 10: the fused kernel; otherwise conv1 -> blocks -> pool + fc through
+        HBM).  ``layers`` (diagnostics): every stage's output, stage after stage (``kws_forward_map_debug_f32``)."""
+        B, _, T, F = (int(v) for v in feat.shape)
+        lab = _ptr(label) if label is not None else None
+        if layers is None:
+            self._check(self._lib.kws_forward_map_f32(self._h, _ptr(feat), B, T, F, _ptr(logits), lab), ModelError)
+        else:
+            self._check(self._lib.kws_forward_map_debug_f32(self._h, _ptr(feat), B, T, F, _ptr(logits), lab, _ptr(layers)), ModelError)
 
     def load_cnn_trad(self, blob: np.ndarray, num_classes: int):
         blob = np.ascontiguousarray(blob, dtype=np.float32)

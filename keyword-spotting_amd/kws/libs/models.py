@@ -161,15 +161,20 @@ class DepthwiseSeparableConv(KeywordSpottingModel):
             raise ModelError(f"{what} needs a CUDA/ROCm tensor: the forward is a HIP kernel and has no CPU fallback")
 
     def forward(self, x: torch.Tensor, return_labels: bool = False):
-        """``float32[B,1,99,10]`` on the GPU -> logits ``float32[B,num_classes]`` (and argmax labels)."""
+        """``float32[B,C,T,F]`` on the GPU -> logits ``float32[B,num_classes]`` (and argmax labels).  Any ``T x F`` the
+        reference's forward accepts (``models.py:160-183``: the pooling is adaptive): 99 x 10 runs the fused LDS-resident
+        kernel, any other map the composed path (``kws_forward_map_f32``)."""
         self._check_input(x, "DepthwiseSeparableConv.forward")
-        if x.dim() != 4 or tuple(x.shape[1:]) != (self.input_channels,) + FEATURE_SHAPE[1:]:
-            raise ModelError(f"expected input [B,{self.input_channels},99,10], got {tuple(x.shape)}")
+        if x.dim() != 4 or x.shape[1] != self.input_channels:
+            raise ModelError(f"expected input [B,{self.input_channels},T,F], got {tuple(x.shape)}")
         ctx = self._context(x.device.index or 0)
         x = x.detach().to(torch.float32).contiguous()
         logits = torch.empty((x.shape[0], self.num_classes), dtype=torch.float32, device=x.device)
         labels = torch.empty((x.shape[0],), dtype=torch.int32, device=x.device)
-        ctx.forward_f32(x, logits, labels)
+        if tuple(x.shape[2:]) == FEATURE_SHAPE[1:]:
+            ctx.forward_f32(x, logits, labels)
+        else:
+            ctx.forward_map_f32(x, logits, labels)
         return (logits, labels) if return_labels else logits
 
     def infer_pcm16(self, wav: torch.Tensor):

@@ -65,6 +65,13 @@ def stress_golden():
 
 
 @pytest.fixture(scope="session")
+def anymap_golden():
+    """DepthwiseSeparableConv on maps other than 99 x 10 (149 x 10, 99 x 13, 20 x 8, 3-channel 50 x 12): inputs, weights, logits,
+    labels and stage outputs of the imported reference model (make_golden.py anymap)."""
+    return np.load(os.path.join(GOLDEN, "anymap_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def dsblock_golden():
     """DepthwiseSeparableConvBlock on its own: inputs, parameters and the imported reference module's outputs."""
     return np.load(os.path.join(GOLDEN, "dsblock_golden.npz"))

@@ -16,6 +16,9 @@ Writes (data only -- inputs and expected outputs, no reference source):
                                     tags -- the 'he' weights, the same with a 5x classifier gain, and weights whose conv1
                                     is NOT pre-divided by the MFCC maps' RMS (activations and logits ~15x larger) ->
                                     reference logits / labels for these 16 + the 48 diverse clips of e2e_golden.npz
+  tests/golden/anymap_golden.npz    DepthwiseSeparableConv on feature maps other than 99 x 10: 149 x 10 (clip_duration_ms=1500),
+                                    99 x 13 (num_cepstral_coeffs=13), a 20 x 8 map and a 3-channel 50 x 12 map -> reference
+                                    logits, labels and every stage's output for two probe inputs
   tests/golden/e2e_golden.npz       48 diverse PCM16 clips + 8 random maps, signal-preserving ("he") weights ->
                                     reference logits / labels / per-layer probes whose VALUES DEPEND ON THE
                                     AUDIO (labels span >= 6 classes, logit std across clips >= 0.1 -- asserted
@@ -330,6 +333,64 @@ def stress_golden():
     print("stress_golden.npz written")
 
 
+def anymap_golden():
+    """DepthwiseSeparableConv.forward takes any [B,C,T,F] (kws/libs/models.py:160-183; adaptive pooling) and AudioConfig's
+    clip_duration_ms / num_cepstral_coeffs change T and F (kws/libs/audio_processor.py:37-46): the imported reference model on
+    such maps -- MFCC maps of 1.5 s clips (149 x 10) and with 13 cepstra (99 x 13), a small random map and a 3-channel one."""
+    div, _ = diverse_clips()
+    rs = np.random.RandomState(77)
+    pick = [3, 4, 9, 15, 18, 23, 30, 40]
+    long_clips = np.concatenate([div[pick], div[pick][:, :8000]], axis=1)          # int16 [8, 24000]: 1.5 s
+    spec_long = o_mfcc.FrontendSpec(n_samples=24000)
+    spec_13 = o_mfcc.FrontendSpec(numcep=13)
+    assert spec_long.num_frames == 149
+    cases = {
+        "t149": torch.from_numpy(np.stack([o_mfcc.extract_features_pcm16(c, spec_long).astype(np.float32) for c in long_clips])[:, None]),
+        "f13": torch.from_numpy(np.stack([o_mfcc.extract_features_pcm16(c, spec_13).astype(np.float32) for c in div[pick]])[:, None]),
+        "small": torch.from_numpy((3.0 * rs.standard_normal((5, 1, 20, 8))).astype(np.float32)),
+        "c3": torch.from_numpy((3.0 * rs.standard_normal((4, 3, 50, 12))).astype(np.float32)),
+    }
+    save = {"long_clips": long_clips, "clips13": div[pick]}
+    for tag, x in cases.items():
+        cin = x.shape[1]
+        ref = ref_models.DepthwiseSeparableConv(num_classes=12, input_channels=cin).eval()
+        st = {}
+        srs = np.random.RandomState(900 + cin)
+        for k, v in ref.state_dict().items():
+            shp = tuple(v.shape)
+            if k.endswith("bias"):
+                w = srs.standard_normal(shp) * 0.1
+            elif k.startswith("fc"):
+                w = srs.standard_normal(shp) * 0.5
+            else:
+                w = srs.standard_normal(shp) * np.sqrt(2.0 / int(np.prod(shp[1:])))
+                if k.startswith("conv1") and tag in ("t149", "f13"):
+                    w = w / 15.0
+            st[k] = torch.from_numpy(w.astype(np.float32))
+        ref.load_state_dict(st)
+        with torch.no_grad():
+            st["fc.bias"] = (st["fc.bias"] - ref(x).mean(0)).float()
+            ref.load_state_dict(st)
+            h = torch.relu(ref.conv1(x)); layers = [h]
+            for blk in (ref.dsconv1, ref.dsconv2, ref.dsconv3, ref.dsconv4):
+                h = blk(h); layers.append(h)
+            logits = ref(x)
+            labels = torch.max(logits, 1)[1]
+        if cin == 1:
+            o_logits = o_dscnn.forward(st, x)
+            np.testing.assert_allclose(o_logits.numpy(), logits.numpy(), rtol=0, atol=2e-6 * float(logits.abs().max()))
+        save[f"{tag}.x"] = x.numpy()
+        save[f"{tag}.blob"] = np.concatenate([st[k].reshape(-1).numpy() for k in ref.state_dict().keys()])
+        save[f"{tag}.logits"] = logits.numpy()
+        save[f"{tag}.label"] = labels.numpy()
+        for i, t in enumerate(layers):
+            save[f"{tag}.layer{i}"] = t[:2].numpy()                       # stage outputs (rings included) of the first two inputs
+        print(f"anymap {tag}: x {tuple(x.shape)} -> stages {[tuple(t.shape[2:]) for t in layers]}, labels {labels.tolist()}, "
+              f"logit std {float(logits.std(0).mean()):.2f}")
+    np.savez_compressed(os.path.join(HERE, "anymap_golden.npz"), **save)
+    print("anymap_golden.npz written")
+
+
 def dsblock_golden():
     """DepthwiseSeparableConvBlock (kws/libs/models.py:75-119) on its own, imported and run: three shapes incl. a
     non-default kernel size / stride / padding and channel counts that are not multiples of the kernel's tiles."""
@@ -392,7 +453,7 @@ def multichannel_golden():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `make_golden.py stress` regenerates one file; no argument = all
-    for name, fn in (("sigproc", sigproc_golden), ("dscnn", dscnn_golden), ("e2e", e2e_golden), ("stress", stress_golden),
+    for name, fn in (("sigproc", sigproc_golden), ("dscnn", dscnn_golden), ("e2e", e2e_golden), ("stress", stress_golden), ("anymap", anymap_golden),
                      ("dsblock", dsblock_golden), ("multichannel", multichannel_golden)):
         if not only or name in only:
             fn()

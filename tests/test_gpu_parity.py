@@ -436,6 +436,93 @@ def test_standalone_block_forward(dev, dsblock_golden):
         blk(torch.zeros(1, 4, 4, 4, device=dev))           # wrong channel count
 
 
+@pytest.mark.parametrize("tag", ["t149", "f13", "small", "c3"])
+def test_dscnn_on_any_feature_map(native, dev, anymap_golden, tag):
+    """DepthwiseSeparableConv.forward accepts any [B,C,T,F] (models.py:160-183): 149 x 10 (clip_duration_ms = 1500), 99 x 13
+    (num_cepstral_coeffs = 13), a 20 x 8 map and a 3-channel 50 x 12 one take the composed path -- conv1, the four blocks with
+    their relu(bias) rings, pool + fc -- and must give the imported reference model's stage outputs (2e-5 of the stage's
+    largest value), logits (1e-4) and labels."""
+    g = anymap_golden
+    x = torch.from_numpy(g[f"{tag}.x"]).to(dev)
+    B, cin, T, F = x.shape
+    c = make_ctx(native)
+    try:
+        c.load_dscnn(g[f"{tag}.blob"], 12, cin)
+        H1, W1 = (T - 6) // 2 + 1, (F - 6) // 2 + 1
+        sizes = [64 * (H1 + 2 * k) * (W1 + 2 * k) for k in range(5)]
+        layers = torch.zeros((B * sum(sizes),), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
+        labels = torch.empty((B,), dtype=torch.int32, device=dev)
+        c.forward_map_f32(x, logits, labels, layers=layers)
+        c.sync()
+        off = 0
+        for k, n in enumerate(sizes):
+            got = layers[off:off + B * n].reshape(B, 64, H1 + 2 * k, W1 + 2 * k)[:2].cpu().numpy()
+            want = g[f"{tag}.layer{k}"]
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), f"stage {k}"
+            if k:  # the ring is relu(bias) exactly, corners included
+                assert np.array_equal(got[:, :, 0, :], want[:, :, 0, :]) and np.array_equal(got[:, :, :, -1], want[:, :, :, -1])
+            off += B * n
+        assert np.abs(logits.cpu().numpy() - g[f"{tag}.logits"]).max() <= TOL
+        assert np.array_equal(labels.cpu().numpy(), g[f"{tag}.label"])
+        # the product entry (no stage dump) gives the same bits
+        l2 = torch.empty_like(logits)
+        c.forward_map_f32(x, l2, None)
+        c.sync()
+        assert torch.equal(l2, logits)
+    finally:
+        c.close()
+
+
+def test_any_map_end_to_end_and_python_surface(native, dev, anymap_golden, e2e_golden):
+    """wav -> label when AudioConfig changes the map: 1.5 s clips (149 frames) and 13 cepstra, through kws_infer_i16 (which
+    follows kws_frontend_shape) and through the drop-in model class; and the composed path on the reference geometry
+    agrees with the fused kernel."""
+    from kws.libs.models import DepthwiseSeparableConv
+
+    g = anymap_golden
+    for tag, clips, kw in (("t149", g["long_clips"], {"n_samples": 24000}), ("f13", g["clips13"], {"numcep": 13})):
+        c = make_ctx(native)
+        try:
+            c.set_frontend(**kw)
+            assert c.frontend_shape() == tuple(g[f"{tag}.x"].shape[2:])
+            c.load_dscnn(g[f"{tag}.blob"], 12)
+            wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
+            logits = torch.empty((len(clips), 12), dtype=torch.float32, device=dev)
+            labels = torch.empty((len(clips),), dtype=torch.int32, device=dev)
+            c.infer_i16(wav, logits, labels)
+            c.sync()
+            assert np.abs(logits.cpu().numpy() - g[f"{tag}.logits"]).max() <= TOL, tag
+            assert np.array_equal(labels.cpu().numpy(), g[f"{tag}.label"]), tag
+        finally:
+            c.close()
+    model = DepthwiseSeparableConv(num_classes=12)
+    st, off = {}, 0
+    for k, shp in o_dscnn.state_shapes(12).items():
+        n = int(np.prod(shp))
+        st[k] = torch.from_numpy(g["t149.blob"][off:off + n].reshape(shp).copy())
+        off += n
+    model.load_state_dict(st)
+    out, lab = model(torch.from_numpy(g["t149.x"]).to(dev), return_labels=True)
+    assert np.abs(out.cpu().numpy() - g["t149.logits"]).max() <= TOL and np.array_equal(lab.cpu().numpy(), g["t149.label"])
+    # 99 x 10 through the composed path (debug entry) vs the fused kernel: two implementations of one network
+    c = make_ctx(native)
+    try:
+        c.load_dscnn(e2e_golden["he.blob"], 12)
+        x = torch.from_numpy(o_mfcc.collate_pcm16(e2e_golden["clips"][:16])).to(dev)
+        fused = torch.empty((16, 12), dtype=torch.float32, device=dev)
+        comp = torch.empty_like(fused)
+        layers = torch.zeros((16 * 64 * (141 + 245 + 357 + 477 + 605),), dtype=torch.float32, device=dev)
+        c.forward_f32(x, fused, None)
+        c.forward_map_f32(x, comp, None, layers=layers)
+        c.sync()
+        assert np.abs(fused.cpu().numpy() - comp.cpu().numpy()).max() <= 2e-5 * float(fused.abs().max())
+        assert np.abs(comp.cpu().numpy() - e2e_golden["he.logits"][8:24]).max() <= TOL
+    finally:
+        c.close()
+
+
 def test_multichannel_model(dev):
     """DepthwiseSeparableConv(input_channels=3) (models.py:125,135): conv1 over three channels in the general kernel, then
     the fused kernel from block 1; logits and labels against the imported reference module's (golden)."""
