@@ -183,8 +183,18 @@ int kws_infer_f32(kws_ctx* ctx, const float* d_wav, int B, float* d_logits, int3
  * are complete on return.  A pinned h_wav (hipHostMalloc / hipHostRegister / torch pin_memory) is read by the DMA
  * directly, without the pack stage. */
 int kws_infer_host_i16(kws_ctx* ctx, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label);
+/* The same in two halves, so that a caller with MANY batches keeps the pipeline full across them (kws_infer_host_i16 alone
+ * fills and drains it inside every call): submit enqueues every chunk of the batch and returns -- the caller's pageable h_wav
+ * has been packed into pinned staging by then and may be reused; a PINNED h_wav, h_logits and h_label must stay valid until
+ * the wait -- and hands back a ticket; kws_infer_host_wait(ctx, ticket) blocks until every batch up to that ticket has its
+ * results in its h_logits / h_label (ticket 0: everything in flight).  Submitting batch k+1 before waiting for batch k lets
+ * k+1's pack and H2D run under k's kernels.  Results of older batches are also delivered whenever a later submit needs
+ * their staging slot.  kws_infer_host_i16 == submit + wait. */
+int kws_infer_host_submit_i16(kws_ctx* ctx, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label, uint64_t* ticket);
+int kws_infer_host_wait(kws_ctx* ctx, uint64_t ticket);
 /* Pipeline shape of kws_infer_host_i16: clips per chunk (default 1024), staging slots in flight (default 3, 2..16), host
- * threads of the pack stage (default min(16, cores/2); negative = pack on the calling thread).  0 keeps a default. */
+ * threads of the pack stage (default min(16, cores/2); negative = pack on the calling thread).  0 keeps a default.  A batch
+ * smaller than chunk x slots is cut into `slots` chunks (not below 128 clips), so that its stages overlap too. */
 int kws_ingest_config(kws_ctx* ctx, int chunk_clips, int n_slots, int pack_threads);
 
 /* Pre-size the internal workspaces for batches up to max_batch (otherwise grown on demand, which
@@ -231,7 +241,8 @@ int kws_stream_close(kws_ctx* ctx);
  * given pointer triple). */
 int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
- * by the context) and the number of pushes so far; the newest frame is row (hops - 3) mod num_frames. */
+ * by the context) and the number of pushes so far; the newest frame is row (hops - K) mod num_frames, K = ceil(frame_len / frame_step)
+ * hops per frame (3 for the reference's 400 / 160). */
 int kws_stream_state(kws_ctx* ctx, const float** d_feat_ring, int* hops);
 /* Copy the raw feature ring (float32 [n_streams, num_frames, numcep], ring order) into caller memory. */
 int kws_stream_copy_features(kws_ctx* ctx, float* d_out);

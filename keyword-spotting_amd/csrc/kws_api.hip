@@ -186,6 +186,7 @@ const char* kws_last_error(kws_ctx* ctx) { return ctx ? ctx->err.c_str() : g_cre
 const char* kws_kernel_name(int id) { return (id >= 0 && id < KWS_K_COUNT) ? kKernelNames[id] : ""; }
 
 int kws_create(kws_ctx** out, int device_id) {
+    KWS_GUARD_BEGIN
     if (!out) return fail(nullptr, KWS_EINVAL, "kws_create: out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -215,6 +216,7 @@ int kws_create(kws_ctx** out, int device_id) {
     }
     *out = c;
     return KWS_OK;
+    KWS_GUARD_END(nullptr, "kws_create")
 }
 
 void kws_destroy(kws_ctx* c) {
@@ -268,6 +270,7 @@ int kws_sync(kws_ctx* c) {
 
 int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, int frame_step, int nfft, int nfilt,
                      int numcep, float preemph, int ceplifter) {
+    KWS_GUARD_BEGIN
     if (!c) return KWS_EINVAL;
     if (sample_rate <= 0 || n_samples <= 0 || frame_len <= 0 || frame_step <= 0 || nfilt <= 0 || numcep <= 0 || nfft < 2)
         return fail(c, KWS_EINVAL, "kws_set_frontend: sizes must be positive");
@@ -405,6 +408,7 @@ int kws_set_frontend(kws_ctx* c, int sample_rate, int n_samples, int frame_len, 
     c->fe_fast_ok = fast;
     c->fe_ready = true;
     return KWS_OK;
+    KWS_GUARD_END(c, "kws_set_frontend")
 }
 
 int kws_set_frontend_math(kws_ctx* c, int math) {
@@ -456,6 +460,7 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
 }
 
 int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_classes, int input_channels) {
+    KWS_GUARD_BEGIN
     if (!c) return KWS_EINVAL;
     if (!blob) return fail(c, KWS_EINVAL, "kws_load_dscnn: blob is NULL");
     if (num_classes < 1 || num_classes > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_load_dscnn: num_classes must be in [1, 64]");
@@ -573,6 +578,7 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->mw.raw = d + o_raw;
     c->model_ready = true;
     return KWS_OK;
+    KWS_GUARD_END(c, "kws_load_dscnn")
 }
 
 // Worklist of the selective refinement for batches of up to B clips: int[8] counters + one entry per frame.  The counters
@@ -914,6 +920,7 @@ static void pack_split8(const float (&v)[8], uint32_t* hi, uint32_t* mid, uint32
 }
 
 int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_classes) {
+    KWS_GUARD_BEGIN
     if (!c) return KWS_EINVAL;
     if (!blob) return fail(c, KWS_EINVAL, "kws_load_cnn_trad: blob is NULL");
     if (num_classes < 1 || num_classes > MAX_CLASSES) return fail(c, KWS_EUNSUPPORTED, "kws_load_cnn_trad: num_classes must be in [1, 64]");
@@ -996,6 +1003,7 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->tw.num_classes = num_classes;
     c->cnntrad_ready = true;
     return KWS_OK;
+    KWS_GUARD_END(c, "kws_load_cnn_trad")
 }
 
 // Grow the context's float scratch (convolution outputs between two kernels of one call) to at least `need` floats.
@@ -1087,7 +1095,7 @@ int kws_stream_vad_f32(kws_ctx* c, float log_energy_threshold, int on_window, in
         c->vad_off = off_window;
     }
     HIP_TRY(c, launch_stream_vad(c->stream, c->d_feat_ring, c->d_hops, c->n_streams, c->fp.num_frames, c->fp.numcep,
-                                 log_energy_threshold, on_window, off_window, c->d_vad_flags, c->d_vad_state, d_state));
+                                 (c->fp.frame_len + c->fp.frame_step - 1) / c->fp.frame_step, log_energy_threshold, on_window, off_window, c->d_vad_flags, c->d_vad_state, d_state));
     return KWS_OK;
 }
 
@@ -1165,7 +1173,8 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         c->prof = was && timed;
         ProfScope ps(c, KWS_K_DSCNN);
         c->prof = was;
-        e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, c->pw_math, nullptr, c->d_hops);
+        e = launch_dscnn(c->stream, c->mw, c->d_feat_ring, c->n_streams, d_logits, d_label, nullptr, c->pw_math, nullptr, c->d_hops, false,
+                         (c->fp.frame_len + c->fp.frame_step - 1) / c->fp.frame_step);
     }
     return e;
 }
@@ -1271,6 +1280,7 @@ int kws_spec512_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame
 }
 
 int kws_spec_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame_len, int nfft, int power, float* d_spec) {
+    KWS_GUARD_BEGIN
     int rc = check_batch(c, d_frames, num_frames, "kws_spec_f32");
     if (rc) return rc;
     if (!d_spec || frame_len <= 0 || nfft < 2) return fail(c, KWS_EINVAL, "kws_spec_f32: bad argument");
@@ -1303,6 +1313,7 @@ int kws_spec_f32(kws_ctx* c, const float* d_frames, int num_frames, int frame_le
     }
     HIP_TRY(c, launch_spec_f64(c->stream, c->d_spec_tw64, d_frames, num_frames, frame_len, nfft, log2n, power, d_spec));
     return KWS_OK;
+    KWS_GUARD_END(c, "kws_spec_f32")
 }
 
 // ---- measurement ---------------------------------------------------------------------------------

@@ -1,6 +1,8 @@
 // The context behind the C ABI (include/kws_hip.h) and the error plumbing shared by the translation units that
 // implement it (kws_api.hip, kws_ingest.hip).
 #pragma once
+#include <new>
+
 #include "kws_internal.h"
 
 namespace kws {
@@ -94,6 +96,13 @@ inline int fail(kws_ctx* c, int code, const std::string& msg) {
 inline int fail_hip(kws_ctx* c, hipError_t e, const char* what) {
     return fail(c, KWS_EHIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+// No exception may cross the C ABI (ctypes would terminate the process): entry points that allocate host containers or
+// start threads run their body between these two.
+#define KWS_GUARD_BEGIN try {
+#define KWS_GUARD_END(c, fn)                                                          \
+    }                                                                                 \
+    catch (const std::bad_alloc&) { return fail(c, KWS_ENOMEM, fn ": out of host memory"); } \
+    catch (...) { return fail(c, KWS_EHIP, fn ": unexpected C++ exception"); }
 #define HIP_TRY(c, expr)                                   \
     do {                                                   \
         hipError_t _e = (expr);                            \

@@ -822,17 +822,20 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     constexpr int FV = (IN_T * IN_F + NT - 1) / NT;
     float fv[FV];
     // streaming: the feature map is a ring of IN_T frames; after `hops` pushes the newest frame sits in row
-    // (hops - 3) mod IN_T and the window starts one row after it
+    // (hops - K) mod IN_T, K = ceil(frame_len / frame_step) hops per frame, and the window starts one row after it
     int row_new = -1;  // STREAM: window row the new frame takes (-1: none yet)
     int head;
     if constexpr (STREAM) {
         hops_before = *sp.hops;
-        head = (((hops_before - 1) % IN_T) + IN_T) % IN_T;  // what the two-launch path derives from the advanced counter
+        // K = hops a frame spans = ceil(frame_len / frame_step) (3 for 400 / 160): after h pushes the newest frame is h - K
+        // and the window starts one row after it; here h = hops_before + 1
+        const int K = (sp.p.frame_len + sp.p.frame_step - 1) / sp.p.frame_step;
+        head = (((hops_before + 2 - K) % IN_T) + IN_T) % IN_T;  // what the two-launch path derives from the advanced counter
         const int step = sp.p.frame_step;
         const long f_start = (long)step * hops_before + step - (long)((sp.p.frame_len + step - 1) / step) * step;
         if (f_start >= 0) row_new = (int)((((f_start / step) - head) % IN_T + IN_T) % IN_T);
     } else {
-        head = ring_hops ? (((*ring_hops - 2) % IN_T) + IN_T) % IN_T : 0;
+        head = ring_hops ? (((*ring_hops + 1 - sp.frames_lag) % IN_T) + IN_T) % IN_T : 0;
     }
 #pragma unroll
     for (int k = 0; k < FV; ++k) {
@@ -1081,8 +1084,10 @@ hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const Strea
 
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps, const int* d_ring_hops,
-                        bool preconv) {
+                        bool preconv, int frames_lag) {
     const size_t lds = LDS_FLOATS * sizeof(float);
+    StreamPush lag{};  // the two-launch streaming route: only the hops-per-frame count travels (the window's first row)
+    lag.frames_lag = frames_lag;
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
     if (preconv) {  // d_feat = conv1 output of a multi-channel model (kws_conv1_general_kernel): product path only
         hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr, StreamPush{});
@@ -1091,17 +1096,17 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
     // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /
     // stencil only; wrong results by construction, reachable only through the diagnostics entry point)
     switch (mode) {
-        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
-        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
-        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
+        case 0: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<0>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
+        case 2: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<2>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
+        case 3: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<3>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
         case 4:
             if (d_act || d_stamps)
-                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{});
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
             else
-                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{});
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
             break;
-        case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
-        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, StreamPush{}); break;
+        case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
+        default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
     }
     return hipGetLastError();
 }
@@ -1200,16 +1205,16 @@ hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, fl
 // (:161); hops before the stream began count as unvoiced (the reference's rings start as zeros).  One thread per stream.
 // state[s] = triggered | event << 1, event 1 = opened at this hop, 2 = closed at this hop.
 __global__ void kws_stream_vad_kernel(const float* __restrict__ feat_ring, const int* __restrict__ hops_ptr, int n_streams,
-                                      int num_frames, int numcep, float threshold, int on_window, int off_window,
+                                      int num_frames, int numcep, int frames_lag, float threshold, int on_window, int off_window,
                                       unsigned char* __restrict__ flags, int* __restrict__ cursor_trig, int32_t* __restrict__ state) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
-    const int hops = *hops_ptr;  // already advanced by the push this call follows: the newest frame is hops - 3
-    if (hops < 3) {              // no complete frame yet
+    const int hops = *hops_ptr;  // already advanced by the push this call follows: the newest frame is hops - K (K hops per frame)
+    if (hops < frames_lag) {     // no complete frame yet
         state[s] = 0;
         return;
     }
-    const float c0 = feat_ring[((size_t)s * num_frames + (hops - 3) % num_frames) * numcep];
+    const float c0 = feat_ring[((size_t)s * num_frames + (hops - frames_lag) % num_frames) * numcep];
     unsigned char* fl = flags + (size_t)s * off_window;
     const int cur = cursor_trig[2 * s];
     int trig = cursor_trig[2 * s + 1];
@@ -1232,10 +1237,10 @@ __global__ void kws_stream_vad_kernel(const float* __restrict__ feat_ring, const
 }
 
 hipError_t launch_stream_vad(hipStream_t s, const float* d_feat_ring, const int* d_hops, int n_streams, int num_frames, int numcep,
-                             float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
+                             int frames_lag, float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
                              int32_t* d_state) {
     hipLaunchKernelGGL(kws_stream_vad_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, s, d_feat_ring, d_hops, n_streams,
-                       num_frames, numcep, threshold, on_window, off_window, d_flags, d_cursor_trig, d_state);
+                       num_frames, numcep, frames_lag, threshold, on_window, off_window, d_flags, d_cursor_trig, d_state);
     return hipGetLastError();
 }
 

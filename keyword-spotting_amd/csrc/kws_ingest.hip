@@ -17,6 +17,8 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <system_error>
 #include <thread>
 
 #include "kws_ctx.h"
@@ -28,7 +30,13 @@ namespace kws {
 class PackPool {
   public:
     explicit PackPool(int n) {
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+        // a host that refuses more threads (cgroup pids limit, RLIMIT_NPROC) still gets a pool: of the threads that did start,
+        // or of none -- copy() then runs on the calling thread.  Nothing is thrown across the C ABI.
+        try {
+            for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+        } catch (const std::system_error&) {
+        }
+        n_started_ = workers_.size();
     }
     ~PackPool() {
         {
@@ -49,7 +57,7 @@ class PackPool {
         dst_ = static_cast<unsigned char*>(dst);
         src_ = static_cast<const unsigned char*>(src);
         bytes_ = bytes;
-        pending_ = (int)workers_.size();
+        pending_ = (int)n_started_;
         ++gen_;
         cv_.notify_all();
         done_.wait(g, [this] { return pending_ == 0; });
@@ -69,7 +77,7 @@ class PackPool {
                 seen = gen_;
                 dst = dst_, src = src_, bytes = bytes_;
             }
-            const size_t n = workers_.size();
+            const size_t n = n_started_;
             const size_t slice = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
             const size_t lo = std::min(bytes, slice * idx), hi = std::min(bytes, lo + slice);
             if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
@@ -80,6 +88,7 @@ class PackPool {
         }
     }
     std::vector<std::thread> workers_;
+    size_t n_started_ = 0;  // fixed before any job is posted (workers_.size() must not be read while the vector may still grow)
     std::mutex m_;
     std::condition_variable cv_, done_;
     unsigned char* dst_ = nullptr;
@@ -98,7 +107,10 @@ struct IngestSlot {
     float* h_logits = nullptr;    // pinned
     int32_t* h_label = nullptr;   // pinned
     hipEvent_t staged = nullptr, computed = nullptr, drained = nullptr;
-    int first = 0, count = 0;     // clips of the user's batch this slot currently carries (count == 0: free)
+    int count = 0;                // clips this slot currently carries (0: free)
+    float* dst_logits = nullptr;  // where its results go in the submitting call's host arrays (already offset to the chunk)
+    int32_t* dst_label = nullptr;
+    uint64_t ticket = 0;          // the submit call it belongs to
 };
 
 struct Ingest {
@@ -107,6 +119,8 @@ struct Ingest {
     std::vector<IngestSlot> slots;
     PackPool* pool = nullptr;
     int pool_threads = 0;
+    uint64_t next_ticket = 1;
+    int next_slot = 0, lane = 0;   // ring position and H2D stream of the next chunk (they persist across submit calls)
     // configuration requested through kws_ingest_config (0 = default)
     int want_chunk = 0, want_slots = 0, want_threads = 0;
 };
@@ -159,8 +173,11 @@ static int ingest_prepare(kws_ctx* c) {
         if (!g->pool) return fail(c, KWS_ENOMEM, "kws_infer_host_i16: out of host memory");
     }
     if (g->chunk == chunk && g->n_slots == n_slots && g->n_samples == n_samples && g->classes == classes) return KWS_OK;
+    for (auto& s : g->slots)
+        if (s.count) return fail(c, KWS_ESTATE, "kws_infer_host_i16: the ingest geometry changed while batches are in flight (kws_infer_host_wait first)");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     ingest_release(g);
+    g->next_slot = g->lane = 0;
     HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_in[0], hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_in[1], hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_out, hipStreamNonBlocking));
@@ -189,12 +206,12 @@ static int ingest_prepare(kws_ctx* c) {
 }
 
 // Results of the chunk a slot carries: wait for its D2H, hand them to the caller, mark the slot free.
-static int ingest_collect(kws_ctx* c, IngestSlot& s, float* h_logits, int32_t* h_label) {
+static int ingest_collect(kws_ctx* c, IngestSlot& s) {
     if (s.count == 0) return KWS_OK;
     HIP_TRY(c, hipEventSynchronize(s.drained));
     const int C = c->ingest->classes;
-    memcpy(h_logits + (size_t)s.first * C, s.h_logits, sizeof(float) * (size_t)s.count * C);
-    if (h_label) memcpy(h_label + s.first, s.h_label, sizeof(int32_t) * (size_t)s.count);
+    memcpy(s.dst_logits, s.h_logits, sizeof(float) * (size_t)s.count * C);
+    if (s.dst_label) memcpy(s.dst_label, s.h_label, sizeof(int32_t) * (size_t)s.count);
     s.count = 0;
     return KWS_OK;
 }
@@ -220,6 +237,9 @@ extern "C" {
 
 int kws_ingest_config(kws_ctx* c, int chunk_clips, int n_slots, int pack_threads) {
     if (!c) return KWS_EINVAL;
+    if (c->ingest)
+        for (auto& s : c->ingest->slots)
+            if (s.count) return fail(c, KWS_ESTATE, "kws_ingest_config: batches are in flight (kws_infer_host_wait first)");
     if (chunk_clips < 0 || n_slots < 0 || (n_slots > 0 && n_slots < 2) || n_slots > 16 || pack_threads > 64)
         return fail(c, KWS_EINVAL, "kws_ingest_config: chunk_clips >= 0, n_slots 0 or 2..16, pack_threads <= 64");
     if (!c->ingest) c->ingest = new (std::nothrow) Ingest();
@@ -230,40 +250,40 @@ int kws_ingest_config(kws_ctx* c, int chunk_clips, int n_slots, int pack_threads
     return KWS_OK;
 }
 
-int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label) {
-    if (!c) return KWS_EINVAL;
-    if (!h_wav || !h_logits) return fail(c, KWS_EINVAL, "kws_infer_host_i16: h_wav and h_logits must not be NULL");
-    if (B <= 0) return fail(c, KWS_EINVAL, "kws_infer_host_i16: B must be positive");
-    if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_host_i16: front end or model not configured");
+// Enqueue one host batch: every chunk is packed (pageable input), sent, computed and its results started on their way back;
+// slots still carrying an older chunk are collected (results copied to THAT chunk's destination) as the ring comes round.
+static int ingest_submit(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label, uint64_t* ticket_out) {
+    if (!h_wav || !h_logits) return fail(c, KWS_EINVAL, "kws_infer_host_submit_i16: h_wav and h_logits must not be NULL");
+    if (B <= 0) return fail(c, KWS_EINVAL, "kws_infer_host_submit_i16: B must be positive");
+    if (!c->fe_ready || !c->model_ready) return fail(c, KWS_ESTATE, "kws_infer_host_submit_i16: front end or model not configured");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ingest_prepare(c);
     if (rc) return rc;
     Ingest* g = c->ingest;
     const int n = g->n_samples, C = g->classes;
-    for (auto& s : g->slots)  // a call that failed half-way left chunks in flight: let them finish, then forget them
-        if (s.count) {
-            HIP_TRY(c, hipDeviceSynchronize());
-            for (auto& t : g->slots) t.count = 0;
-            break;
-        }
     const int kind = host_pointer_kind(h_wav);
     if (kind < 0 || host_pointer_kind(h_logits) < 0 || (h_label && host_pointer_kind(h_label) < 0))
-        return fail(c, KWS_EINVAL, "kws_infer_host_i16: h_wav / h_logits / h_label must be HOST pointers (device tensors go to kws_infer_i16)");
+        return fail(c, KWS_EINVAL, "kws_infer_host_submit_i16: h_wav / h_logits / h_label must be HOST pointers (device tensors go to kws_infer_i16)");
     const bool direct = kind == 1;  // the DMA can read the caller's buffer: no pack stage
-    int next = 0, lane = 0;
-    for (int first = 0; first < B; first += g->chunk, next = (next + 1) % g->n_slots, lane ^= 1) {
-        IngestSlot& s = g->slots[next];
-        rc = ingest_collect(c, s, h_logits, h_label);  // blocks only if this slot's previous chunk is still in flight
+    // Chunk size of THIS batch: a batch smaller than the ring (the reference's own batch_size = 1028, train.py:110, against
+    // 3 x 1024) would otherwise be one chunk plus a tail, its pack / H2D / compute / D2H strictly one after the other; cut
+    // into as many chunks as there are slots (not below 128 clips: a launch pair per chunk costs ~0.1 ms of fixed time).
+    int chunk = (B + g->n_slots - 1) / g->n_slots;
+    chunk = std::min(g->chunk, std::max(chunk, std::min(B, 128)));  // never above what the staging slots hold
+    const uint64_t ticket = g->next_ticket++;
+    for (int first = 0; first < B; first += chunk, g->next_slot = (g->next_slot + 1) % g->n_slots, g->lane ^= 1) {
+        IngestSlot& s = g->slots[g->next_slot];
+        rc = ingest_collect(c, s);  // blocks only if this slot's previous chunk is still in flight
         if (rc) return rc;
-        const int count = std::min(g->chunk, B - first);
+        const int count = std::min(chunk, B - first);
         const size_t bytes = sizeof(int16_t) * (size_t)count * n;
         const int16_t* src = h_wav + (size_t)first * n;
         if (!direct) {
             g->pool->copy(s.h_in, src, bytes);
             src = s.h_in;
         }
-        HIP_TRY(c, hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, g->copy_in[lane]));
-        HIP_TRY(c, hipEventRecord(s.staged, g->copy_in[lane]));
+        HIP_TRY(c, hipMemcpyAsync(s.d_in, src, bytes, hipMemcpyHostToDevice, g->copy_in[g->lane]));
+        HIP_TRY(c, hipEventRecord(s.staged, g->copy_in[g->lane]));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, s.staged, 0));
         rc = kws_infer_i16(c, s.d_in, count, s.d_logits, s.d_label);
         if (rc) return rc;
@@ -272,14 +292,66 @@ int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits,
         HIP_TRY(c, hipMemcpyAsync(s.h_logits, s.d_logits, sizeof(float) * (size_t)count * C, hipMemcpyDeviceToHost, g->copy_out));
         HIP_TRY(c, hipMemcpyAsync(s.h_label, s.d_label, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost, g->copy_out));
         HIP_TRY(c, hipEventRecord(s.drained, g->copy_out));
-        s.first = first;
+        s.dst_logits = h_logits + (size_t)first * C;
+        s.dst_label = h_label ? h_label + first : nullptr;
+        s.ticket = ticket;
         s.count = count;
     }
-    for (int i = 0; i < g->n_slots; ++i) {  // oldest first
-        rc = ingest_collect(c, g->slots[(next + i) % g->n_slots], h_logits, h_label);
-        if (rc) return rc;
+    if (ticket_out) *ticket_out = ticket;
+    return KWS_OK;
+}
+
+// Collect every chunk of the batches up to `ticket` (0: everything in flight), oldest first.
+static int ingest_wait(kws_ctx* c, uint64_t ticket) {
+    Ingest* g = c->ingest;
+    if (!g || g->slots.empty()) return KWS_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int i = 0; i < g->n_slots; ++i) {
+        IngestSlot& s = g->slots[(g->next_slot + i) % g->n_slots];
+        if (s.count && (ticket == 0 || s.ticket <= ticket)) {
+            int rc = ingest_collect(c, s);
+            if (rc) {  // a failed D2H: let the device finish, then forget what was in flight (the caller's arrays stay partial)
+                (void)hipDeviceSynchronize();
+                for (auto& t : g->slots) t.count = 0;
+                return rc;
+            }
+        }
     }
     return KWS_OK;
+}
+
+int kws_infer_host_submit_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label, uint64_t* ticket) {
+    if (!c) return KWS_EINVAL;
+    try {
+        int rc = ingest_submit(c, h_wav, B, h_logits, h_label, ticket);
+        if (rc) {  // a call that failed half-way may have left chunks in flight: let them finish, then forget them
+            (void)hipDeviceSynchronize();
+            if (c->ingest)
+                for (auto& t : c->ingest->slots) t.count = 0;
+        }
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return fail(c, KWS_ENOMEM, "kws_infer_host_submit_i16: out of host memory");
+    } catch (...) {
+        return fail(c, KWS_EHIP, "kws_infer_host_submit_i16: unexpected C++ exception");
+    }
+}
+
+int kws_infer_host_wait(kws_ctx* c, uint64_t ticket) {
+    if (!c) return KWS_EINVAL;
+    try {
+        return ingest_wait(c, ticket);
+    } catch (...) {
+        return fail(c, KWS_EHIP, "kws_infer_host_wait: unexpected C++ exception");
+    }
+}
+
+int kws_infer_host_i16(kws_ctx* c, const int16_t* h_wav, int B, float* h_logits, int32_t* h_label) {
+    if (!c) return KWS_EINVAL;
+    uint64_t ticket = 0;
+    int rc = kws_infer_host_submit_i16(c, h_wav, B, h_logits, h_label, &ticket);
+    if (rc) return rc;
+    return kws_infer_host_wait(c, ticket);
 }
 
 }  // extern "C"

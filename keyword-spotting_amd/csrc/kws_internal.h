@@ -164,12 +164,13 @@ struct StreamPush {
     int ring_len;
     int* hops;
     int* refine_ctr;         // counters of the selective refinement (RefineList::ctr; [5] counts frames redone by pushes) or NULL
+    int frames_lag;          // two-launch route only: hops a frame spans, ceil(frame_len / frame_step) (the fused push derives it from p)
 };
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
                                float* d_logits, int32_t* d_label);
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
-                        const int* d_ring_hops = nullptr, bool preconv = false);
+                        const int* d_ring_hops = nullptr, bool preconv = false, int frames_lag = 3);
 // conv1 of a model with input_channels > 1: x [B][C_in][99][10] -> relu(conv1) [B][64][141]; d_wt = weights as [ci][tap][co]
 hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in, const float* d_wt, const float* d_bias, float* d_out);
 
@@ -209,7 +210,7 @@ hipError_t launch_softmax(hipStream_t s, const float* d_logits, int B, int C, fl
 hipError_t launch_smooth_posteriors(hipStream_t s, const float* d_logits, int S, int C, int window, float* d_ring,
                                     float* d_sum, int* d_count, float* d_smoothed, int32_t* d_label);
 hipError_t launch_stream_vad(hipStream_t s, const float* d_feat_ring, const int* d_hops, int n_streams, int num_frames, int numcep,
-                             float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
+                             int frames_lag, float threshold, int on_window, int off_window, unsigned char* d_flags, int* d_cursor_trig,
                              int32_t* d_state);
 
 extern const char* const kKernelNames[KWS_K_COUNT];

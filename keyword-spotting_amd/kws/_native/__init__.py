@@ -56,6 +56,8 @@ SIGNATURES = {
                                           C.c_int, C.c_int, _f32p]),
     "kws_infer_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
     "kws_infer_host_i16": (C.c_int, [_c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "kws_infer_host_submit_i16": (C.c_int, [_c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "kws_infer_host_wait": (C.c_int, [_c_ctx, C.c_uint64]),
     "kws_ingest_config": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_int]),
     "kws_reserve": (C.c_int, [_c_ctx, C.c_int]),
     "kws_set_pointwise_math": (C.c_int, [_c_ctx, C.c_int]),
@@ -276,6 +278,18 @@ class Context:
     def infer_host_i16(self, wav: np.ndarray, logits: np.ndarray = None, label: np.ndarray = None):
         """Host ``int16[B,n]`` (numpy array or CPU torch tensor, pageable or pinned) -> host (logits float32[B,C], labels
         int32[B]) through the library's pack / H2D / compute / D2H pipeline (``kws_infer_host_i16``)."""
+        logits, label, ticket, _keep = self.infer_host_submit_i16(wav, logits, label)
+        self.infer_host_wait(ticket)
+        return logits, label
+
+    def infer_host_wait(self, ticket: int = 0):
+        """Block until every submitted batch up to ``ticket`` (0: all) has its results in its host arrays."""
+        self._check(self._lib.kws_infer_host_wait(self._h, C.c_uint64(int(ticket))), ModelError)
+
+    def infer_host_submit_i16(self, wav: np.ndarray, logits: np.ndarray = None, label: np.ndarray = None):
+        """Enqueue one host batch without waiting for its results (``kws_infer_host_submit_i16``).  Returns (logits, label,
+        ticket, keepalive): the arrays are filled once ``infer_host_wait(ticket)`` has returned; keep ``keepalive`` (the
+        source buffer -- a pinned one is read by the DMA until then) referenced until that wait."""
         if self.num_classes is None:
             raise ModelError("no model loaded (kws_load_dscnn)")
         if hasattr(wav, "data_ptr"):  # CPU torch tensor (possibly pinned)
@@ -293,9 +307,10 @@ class Context:
             label = np.empty((B,), np.int32)
         assert logits.dtype == np.float32 and logits.flags.c_contiguous and logits.shape == (B, self.num_classes)
         assert label.dtype == np.int32 and label.flags.c_contiguous and label.shape == (B,)
-        self._check(self._lib.kws_infer_host_i16(self._h, C.c_void_p(src), B, C.c_void_p(logits.ctypes.data),
-                                                 C.c_void_p(label.ctypes.data)), ModelError)
-        return logits, label
+        ticket = C.c_uint64(0)
+        self._check(self._lib.kws_infer_host_submit_i16(self._h, C.c_void_p(src), B, C.c_void_p(logits.ctypes.data),
+                                                        C.c_void_p(label.ctypes.data), C.byref(ticket)), ModelError)
+        return logits, label, int(ticket.value), wav
 
     def ingest_config(self, chunk_clips: int = 0, n_slots: int = 0, pack_threads: int = 0):
         self._check(self._lib.kws_ingest_config(self._h, int(chunk_clips), int(n_slots), int(pack_threads)), ModelError)

@@ -42,21 +42,38 @@ class KeywordSpotter:
     def infer_batches(self, batches: Iterable[np.ndarray], max_batch: Optional[int] = None
                       ) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
         """Host ingest for many batches: every ``int16[B,n]`` host batch (numpy array, or a CPU
-        torch tensor -- a pinned one is read by the DMA directly, without the pack stage) goes through
-        ``kws_infer_host_i16``: chunks of 1024 clips, a pool of host threads packing chunk k+1 into pinned staging while
-        chunk k crosses PCIe on a copy stream, chunk k-1 runs MFCC + DS-CNN and the results of chunk k-2 return on a
-        second copy stream.  Yields ``(labels int32[B], logits float32[B,C])`` per batch, in order.  ``max_batch`` is
-        accepted for compatibility (the staging rings are sized per chunk, not per batch)."""
+        torch tensor -- a pinned one is read by the DMA directly, without the pack stage) goes through the library's
+        pipeline: a pool of host threads packs chunk k+1 into pinned staging while chunk k crosses PCIe on a copy stream,
+        chunk k-1 runs MFCC + DS-CNN and the results of chunk k-2 return on a second copy stream.  The pipeline stays
+        full ACROSS batches: batch k+1 is submitted (``kws_infer_host_submit_i16``) before batch k's results are waited
+        for, so its pack and H2D run under batch k's kernels -- with the reference's own batch size (1028, ``train.py:110``)
+        a batch is also cut into as many chunks as the ring has slots.  Yields ``(labels int32[B], logits float32[B,C])``
+        per batch, in order.  ``max_batch``: clips per chunk of the staging ring (default 1024)."""
         n = self.config.desired_samples
         ctx = self.model._context(self.device.index or 0)
-        for batch in batches:
-            if torch.is_tensor(batch) and batch.dtype == torch.int16 and batch.dim() == 2 and batch.shape[1] == n \
-                    and not batch.is_cuda and batch.is_contiguous():
-                src = batch
-            else:
-                src = np.ascontiguousarray(fix_length(np.atleast_2d(np.asarray(batch, dtype=np.int16)), n))
-            logits, labels = ctx.infer_host_i16(src)
-            yield labels, logits
+        if max_batch:
+            ctx.infer_host_wait(0)
+            ctx.ingest_config(chunk_clips=int(max_batch))
+        pending = None  # (logits, labels, ticket, keepalive) of the batch submitted last
+        try:
+            for batch in batches:
+                if torch.is_tensor(batch) and batch.dtype == torch.int16 and batch.dim() == 2 and batch.shape[1] == n \
+                        and not batch.is_cuda and batch.is_contiguous():
+                    src = batch
+                else:
+                    src = np.ascontiguousarray(fix_length(np.atleast_2d(np.asarray(batch, dtype=np.int16)), n))
+                nxt = ctx.infer_host_submit_i16(src)
+                if pending is not None:
+                    ctx.infer_host_wait(pending[2])
+                    yield pending[1], pending[0]
+                pending = nxt
+            if pending is not None:
+                ctx.infer_host_wait(pending[2])
+                yield pending[1], pending[0]
+                pending = None
+        finally:
+            if pending is not None:  # the consumer stopped early: nothing may stay in flight into freed arrays
+                ctx.infer_host_wait(0)
 
     def infer_files(self, paths: Sequence[str], resample: bool = False) -> List[Tuple[int, str]]:
         """wav files -> (index, word).  16-bit mono files at the configured rate go through the int16 path (the PCM
@@ -128,6 +145,12 @@ class StreamingSpotter:
         self.device = torch.device("cuda", device)
         self.use_graph = use_graph
         self._ctx = _native.Context(device, ModelError)
+        cfg = self.config
+        frame_len = int(round(cfg.frame_length * cfg.sample_rate))
+        if (cfg.sample_rate, cfg.desired_samples, frame_len, self.hop, cfg.fft_size, cfg.num_mel_filters, cfg.num_cepstral_coeffs) != \
+                (16000, 16000, 400, 160, 512, 26, 10):  # a non-default AudioConfig: tell the front end (nfft as audio_processor.py:268 derives it)
+            self._ctx.set_frontend(cfg.sample_rate, cfg.desired_samples, frame_len, self.hop, max(cfg.fft_size, frame_len),
+                                   cfg.num_mel_filters, cfg.num_cepstral_coeffs)
         self._ctx.load_dscnn(self.model.packed_weights(), self.model.num_classes)
         self._ctx.stream_open(self.n_streams)
         self._hop_buf = torch.zeros((self.n_streams, self.hop), dtype=torch.int16, device=self.device)
@@ -186,7 +209,9 @@ class StreamingSpotter:
         self._ctx.stream_copy_features(tmp)
         self._ctx.sync()
         host = tmp.cpu().numpy()
-        head = (hops - 2) % t
+        frame_len = int(round(self.config.frame_length * self.config.sample_rate))
+        k = -(-frame_len // self.hop)       # hops a frame spans (3 for 400 / 160): the newest frame is hops - k
+        head = (hops - k + 1) % t
         return np.roll(host, -head, axis=1), hops
 
     def close(self):

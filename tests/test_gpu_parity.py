@@ -966,6 +966,52 @@ def test_streaming_high_dynamic_range_streams_meet_the_gate(native, dev, e2e_gol
         fo.close()
 
 
+@pytest.mark.parametrize("route", ["one_launch", "two_launch"])
+def test_streaming_with_two_hops_per_frame(native, dev, e2e_golden, route):
+    """A 20 ms window (320 samples) over 10 ms hops still gives 99 frames per second, but a frame now spans TWO hops, not
+    three: the newest frame after h pushes is h - 2 and the window starts at row (h - 1) mod 99.  Every place that derives
+    the window's first row (fused push, two-launch push, endpointer, host mirror) takes it from ceil(frame_len / step)."""
+    from kws.inference import StreamingSpotter
+    from kws.libs.audio_processor import AudioConfig
+
+    S, hops = 3, 108
+    cfg = AudioConfig(frame_length=0.02)
+    spec = lambda n: o_mfcc.FrontendSpec(winlen=0.02, n_samples=n)
+    model = he_model(e2e_golden)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    pcm = np.random.default_rng(91).integers(-20000, 20000, size=(S, hops * 160), dtype=np.int16)
+    pcm[1] //= 40
+    sp = StreamingSpotter(S, model, config=cfg, vad_log_energy=-3.0)
+    try:
+        if route == "two_launch":
+            sp._ctx.set_pointwise_math(native.PW_F32)
+        for t in range(hops):
+            labels, logits = sp.push(pcm[:, t * 160:(t + 1) * 160])
+            if t not in (1, 2, 50, 98, 99, 100, hops - 1):
+                continue
+            feats, pushed = sp.features()
+            assert pushed == t + 1
+            newest = t - 1
+            want = np.zeros((S, 99, 10), np.float32)
+            for s in range(S):
+                allf = o_mfcc.mfcc(o_mfcc.pcm16_to_float(pcm[s, : (t + 1) * 160]), spec((t + 1) * 160))
+                for i in range(99):
+                    f = newest - 98 + i
+                    if 0 <= f <= newest:
+                        want[s, i] = allf[f]
+            assert np.abs(feats - want).max() <= TOL, f"hop {t}"
+            ref = o_dscnn.forward(state, torch.from_numpy(want)[:, None])
+            err = float(np.abs(logits - ref.numpy()).max())
+            assert err <= (TOL if route == "one_launch" else 5e-5 * max(1.0, float(ref.abs().max()))), f"hop {t}: {err:.3e}"
+            # the endpointer reads the newest frame's log energy: loud streams voiced, the quiet one not
+            want_voiced = want[:, -1, 0] > -3.0
+            assert sp.vad_state is not None
+            if t >= 60:
+                assert np.array_equal((sp.vad_state & 1).astype(bool), want_voiced), (t, sp.vad_state, want[:, -1, 0])
+    finally:
+        sp.close()
+
+
 def test_streaming_one_launch_push_agrees_with_the_two_launch_path(native, dev, e2e_golden):
     """A push that asks for logits from the product DS-CNN is one launch (each stream's new frame is computed in the prologue
     of its DS-CNN workgroup); a features-only push, and a push under the f32-MFMA pointwise variant, take the separate frame
@@ -1071,6 +1117,9 @@ def test_host_ingest_pipeline(native, dev, e2e_golden):
     big[100:148] = e2e_golden["clips"]
     want_logits, want_labels = model.infer_pcm16(torch.from_numpy(big).to(dev))
     want_logits, want_labels = want_logits.cpu().numpy(), want_labels.cpu().numpy()
+    # not only HIP path against HIP path: the 48 golden clips inside the batch against the imported reference model's values
+    assert np.abs(want_logits[100:148] - e2e_golden["he.logits"][8:]).max() <= TOL
+    assert np.array_equal(want_labels[100:148], e2e_golden["he.label"][8:])
     c = native.Context(0)
     try:
         c.load_dscnn(e2e_golden["he.blob"], 12)
@@ -1079,6 +1128,8 @@ def test_host_ingest_pipeline(native, dev, e2e_golden):
             n = 2500 if chunk != 1 else 40
             logits, labels = c.infer_host_i16(big[:n])
             assert np.array_equal(logits, want_logits[:n]) and np.array_equal(labels, want_labels[:n]), (chunk, slots, threads)
+            if n > 148:
+                assert np.abs(logits[100:148] - e2e_golden["he.logits"][8:]).max() <= TOL   # the ingest route itself vs the reference
         c.ingest_config(0, 0, 0)
         for n in (1, 1023, 1024, 1025, 2049):
             logits, labels = c.infer_host_i16(big[:n])
@@ -1110,6 +1161,36 @@ def test_host_ingest_pipeline(native, dev, e2e_golden):
     padded = np.concatenate([big[:10, :15000], np.zeros((10, 1000), np.int16)], axis=1)
     wl, _ = model.infer_pcm16(torch.from_numpy(padded).to(dev))
     assert np.array_equal(logits, wl.cpu().numpy())
+
+
+def test_infer_batches_keeps_the_pipeline_full_across_small_batches(native, dev, e2e_golden):
+    """KeywordSpotter.infer_batches over batches of the reference's own size (1028, train.py:110) and smaller ones: batch k+1
+    is submitted before batch k is waited for, every batch is cut into as many chunks as the ring has slots -- and every
+    result equals the device-resident call's, bit for bit."""
+    from kws.inference import KeywordSpotter
+
+    model = he_model(e2e_golden)
+    spotter = KeywordSpotter(model)
+    sizes = [1028, 256, 1028, 5, 130, 3000]
+    big = np.concatenate([synth_clips(s, 60 + i) for i, s in enumerate(sizes)])
+    big[7:7 + 48] = e2e_golden["clips"]
+    want_logits, want_labels = gpu_infer(model._context(dev.index or 0), dev, big)
+    assert np.abs(want_logits[7:7 + 48] - e2e_golden["he.logits"][8:]).max() <= TOL       # anchored on the reference model's logits
+    off = 0
+    batches = []
+    for s_ in sizes:
+        batches.append(big[off:off + s_])
+        off += s_
+    got = list(spotter.infer_batches(iter(batches)))
+    assert [len(lab) for lab, _ in got] == sizes
+    assert np.array_equal(np.concatenate([lab for lab, _ in got]), want_labels)
+    assert np.array_equal(np.concatenate([lg for _, lg in got]), want_logits)
+    # a consumer that stops early leaves nothing in flight
+    it = spotter.infer_batches(iter(batches))
+    next(it)
+    it.close()
+    lab, lg = spotter.infer_pcm16(batches[1])
+    assert np.array_equal(lg, want_logits[1028:1028 + 256])
 
 
 def test_mfcc_batch_beyond_grid_limit(ctx, dev):
