@@ -165,6 +165,40 @@ def host_cores() -> int:
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def gpu_numa_cpus(index: int):
+    """(numa node, set of CPUs local to it) of the index-th GPU, read from sysfs WITHOUT touching HIP (the caller pins
+    itself before the runtime starts): KFD topology node -> PCI address -> numa_node / local_cpulist.  None when the
+    host does not expose it (containers often hide /sys/class/kfd)."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = {}
+            with open(os.path.join(base, node, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:  # a GPU node (CPU nodes have no SIMDs)
+                gpus.append(props)
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if visible:
+            order = [int(v) for v in visible.split(",") if v.strip().isdigit()]
+            gpus = [gpus[i] for i in order if i < len(gpus)]
+        pr = gpus[index]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        addr = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+            node = int(f.read().strip())
+        with open(f"/sys/bus/pci/devices/{addr}/local_cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        return node, cpus
+    except Exception:
+        return None
+
+
 # ------------------------------------------------------------------------------------------ CPU baseline (oracle)
 def _mfcc_chunk(chunk):  # process-pool worker: module-level so that spawn can import it
     from oracle import psf_mfcc as o_mfcc
@@ -527,6 +561,92 @@ def leg_cnn_trad(args, _native, torch, dev, B, cpu_n):
     return out
 
 
+def leg_batch1(args, _native, torch, dev, blob, cpu_check):
+    """BASELINE.json configs[0]: batch = 1 -- the reference's own CPU-runnable case ("10-keyword cnn-trad-fpool3, batch=1 on
+    reference CPU path").  GPU latency of ONE clip wav -> label (host wall time from the call to the label being complete,
+    the clip already in device memory) for the reference's model (DS-CNN) and for the build-defined cnn-trad-fpool3, next
+    to the same clip on the CPU oracle (per-clip NumPy MFCC + torch-CPU forward at batch 1)."""
+    out = {"workload": "configs[0]: batch=1, one synthetic 1s/16kHz clip, wav -> label; GPU latency (device-resident clip, call -> label "
+                       "complete) beside the CPU path at batch 1"}
+    clips = synth_clips(64, seed=103)
+    wav = torch.from_numpy(clips).to(dev)
+    logits = torch.empty((1, NUM_CLASSES), dtype=torch.float32, device=dev)
+    labels = torch.empty((1,), dtype=torch.int32, device=dev)
+    ct_state = synth_cnn_trad_weights()
+    for model in ("ds-cnn", "cnn-trad-fpool3"):
+        ctx = _native.Context(dev.index)
+        if model == "ds-cnn":
+            ctx.load_dscnn(blob, NUM_CLASSES)
+            call = lambda i: ctx.infer_i16(wav[i:i + 1], logits, labels)
+        else:
+            ctx.load_cnn_trad(ct_state, NUM_CLASSES)
+            call = lambda i: ctx.infer_cnn_trad_i16(wav[i:i + 1], logits, labels)
+        ctx.reserve(1)
+        for i in range(300):
+            call(i % 64)
+        ctx.sync()
+        lat = []
+        for i in range(400):
+            t0 = time.perf_counter()
+            call(i % 64)
+            ctx.sync()
+            lat.append((time.perf_counter() - t0) * 1e6)
+        lat = np.array(lat)
+        row = {"gpu_latency_us_p50": float(np.percentile(lat, 50)), "gpu_latency_us_p99": float(np.percentile(lat, 99)),
+               "gpu_clips_per_s_at_batch_1": 1e6 / float(np.percentile(lat, 50))}
+        ctx.prof_enable(1)
+        ctx.prof_reset()
+        for i in range(50):
+            call(i % 64)
+        ctx.sync()
+        kern = {}
+        for kid in range(7):
+            ms, n = ctx.prof_read(kid)
+            if n:
+                kern[_native.kernel_name(kid)] = ms / n * 1e3
+        row["kernel_us"] = kern
+        ctx.prof_enable(False)
+        got = logits.cpu().numpy().copy()  # clip 49 (the last call)
+        if cpu_check:
+            import torch as _t
+
+            from oracle import psf_mfcc as o_mfcc
+
+            _t.set_num_threads(1)
+            if model == "ds-cnn":
+                from oracle import dscnn as o_net
+
+                state, off = {}, 0
+                for k, shp in o_net.state_shapes(NUM_CLASSES).items():
+                    n = int(np.prod(shp))
+                    state[k] = _t.from_numpy(blob[off:off + n].reshape(shp).copy())
+                    off += n
+                fwd = lambda x: o_net.forward(state, x)
+            else:
+                from oracle import cnn_trad as o_net
+
+                state = o_net.unflatten_state(ct_state, NUM_CLASSES)
+                fwd = lambda x: o_net.forward(state, x)
+            ts = []
+            with _t.no_grad():
+                for i in range(12):
+                    t0 = time.perf_counter()
+                    want = fwd(_t.from_numpy(o_mfcc.collate_pcm16(clips[49:50])))
+                    ts.append(time.perf_counter() - t0)
+            row["cpu_latency_ms_median"] = _median(ts[2:]) * 1e3
+            row["cpu_threads"] = 1
+            row["max_abs_logit_err_vs_cpu_over_scale"] = float(np.abs(got - want.numpy()).max() / max(1.0, float(want.abs().max())))
+        out[model] = row
+        ctx.close()
+    out["value"] = out["ds-cnn"]["gpu_latency_us_p50"]
+    out["unit"] = "us p50 per clip (DS-CNN, batch 1)"
+    out["higher_is_better"] = False
+    out["cpu_model"] = cpu_model_string()
+    out["note"] = ("latency, not throughput: one clip occupies 5 workgroups of the MFCC kernel and ONE of the DS-CNN kernel (1 of 256 CUs); "
+                   "the throughput configurations are C2-C4")
+    return out
+
+
 def leg_dscnn_shard(args, _native, torch, dev, blob, B):
     """BASELINE.json configs[3]'s per-GPU shape: DS-CNN fused on one 1024-clip shard of the 8192-clip batch."""
     ctx = _native.Context(dev.index)
@@ -643,6 +763,16 @@ def worker(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    numa = None
+    if args.ingest == "host" and not args.selftest_cpu:
+        # host-fed run: this rank's host threads (pack pool) and its pinned staging rings belong on the GPU's NUMA node --
+        # pin the process BEFORE torch / HIP start (threads and first-touch allocations inherit it)
+        numa = gpu_numa_cpus(local_rank)
+        if numa and numa[1] and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, numa[1] & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+            except OSError:
+                numa = None
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: either unset WORLD_SIZE (bench.py launches its own ranks) "
                          f"or start it with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -740,7 +870,16 @@ def worker(args) -> int:
         wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
         logits = torch.empty((B, NUM_CLASSES), dtype=torch.float32, device=dev)
         labels = torch.empty((B,), dtype=torch.int32, device=dev)
-        if args.model == "mfcc-only":
+        host_logits = host_labels = None
+        if args.ingest == "host":
+            if args.model != "ds-cnn":
+                raise SystemExit("--ingest host is the DS-CNN wav -> label path (kws_infer_host_i16)")
+            ctx.load_dscnn(blob, NUM_CLASSES)
+            host_clips = np.ascontiguousarray(clips)              # pageable host memory, as a DataLoader hands batches over
+            host_logits = np.empty((B, NUM_CLASSES), np.float32)
+            host_labels = np.empty((B,), np.int32)
+            step = lambda: ctx.infer_host_i16(host_clips, host_logits, host_labels)
+        elif args.model == "mfcc-only":
             feat_out = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
             step = lambda: ctx.mfcc_i16(wav, feat_out)
         elif args.model == "cnn-trad-fpool3":
@@ -833,6 +972,15 @@ def worker(args) -> int:
                                 "algorithmic_tflops": CNNTRAD_CONV_FLOP_PER_CLIP * B / conv_s / 1e12 if conv_s > 0 else 0.0},
                    "other_kernels_ms": {_native.kernel_name(_native.KWS_K_MFCC): mfcc_ms,
                                         _native.kernel_name(_native.KWS_K_CNNTRAD_DENSE): d_ms / max(d_n, 1)}, **multi}
+        elif args.ingest == "host":
+            out = {"metric": "1s 16kHz clips/sec end-to-end (wav->label), HOST-FED: pageable host int16 in, host logits + labels out (PCIe inclusive)",
+                   "value": value, "unit": "clips/s", **common,
+                   "config": {"workload": f"DS-CNN end to end from HOST memory: batch={B}/GPU synthetic uniform int16 clips in pageable host memory -> "
+                                          "kws_infer_host_i16 (pack threads -> pinned rings -> H2D || MFCC + DS-CNN || D2H) -> host logits+label", **cfg,
+                              "ingest": "host", "numa": ({"node": numa[0], "cpus_pinned": len(numa[1])} if numa else "not exposed by this host")},
+                   "not_the_headline": "the contract's `value` is the device-resident rate (run without --ingest host); this line is the PCIe-inclusive rate",
+                   "h2d_GBps_per_gpu": value / world * BYTES_PER_CLIP / 1e9, **multi}
+            out["labels_seen"] = {"n_classes": int(len(np.unique(host_labels)))}
         else:
             out = {
                 "metric": "1s 16kHz clips/sec end-to-end (wav->label)", "value": value, "unit": "clips/s", **common,
@@ -877,7 +1025,8 @@ def worker(args) -> int:
                 ctx = None
                 cpu_n = args.cpu_sample
                 legs = {}
-                for name, fn in (("C2_mfcc_only", lambda: leg_mfcc_only(args, _native, torch, dev, 4096, min(cpu_n, 256))),
+                for name, fn in (("C1_batch1", lambda: leg_batch1(args, _native, torch, dev, blob, cpu_n > 0)),
+                                 ("C2_mfcc_only", lambda: leg_mfcc_only(args, _native, torch, dev, 4096, min(cpu_n, 256))),
                                  ("C2_mfcc_only_float64", lambda: leg_mfcc_only(args, _native, torch, dev, 4096, min(cpu_n, 256), precise=True)),
                                  ("C3_cnn_trad_fpool3", lambda: leg_cnn_trad(args, _native, torch, dev, 4096, min(cpu_n, 64))),
                                  ("C4_dscnn_shard_1024", lambda: leg_dscnn_shard(args, _native, torch, dev, blob, 1024)),
@@ -921,6 +1070,9 @@ def parse_args(argv=None):
                          "collective): gloo over 127.0.0.1 by default -- nothing to gain from RCCL for two scalars -- or nccl (= RCCL)")
     ap.add_argument("--frontend-math", choices=["f32", "f64"], default="f32",
                     help="f32: the fast front end (default, the headline); f64: KWS_FE_F64, float64 after framing as psf computes it")
+    ap.add_argument("--ingest", choices=["device", "host"], default="device",
+                    help="device: inputs resident in HBM when the timed region starts (the contract's `value`); host: the timed step is "
+                         "kws_infer_host_i16 on pageable host memory (PCIe inclusive), each rank pinned to its GPU's NUMA node")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the extra launch on the golden clips after the timed region (profile runs: exact launch counts)")
     ap.add_argument("--prof-every", type=int, default=8,

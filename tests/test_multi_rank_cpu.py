@@ -84,3 +84,23 @@ def test_cnn_trad_bench_weights_match_the_oracle_layout():
     assert list(state) == list(shapes) and all(tuple(state[k].shape) == shapes[k] for k in shapes)
     assert np.array_equal(o_ct.flatten_state(state), blob)
     assert abs(float(state["conv2.weight"].std()) - (2.0 / 2560) ** 0.5) < 2e-3  # fan-in scaled
+
+
+def test_scale_sweep_builds_the_table_from_fresh_children(tmp_path):
+    """tools/scale_sweep.py: every point a fresh `bench.py --gpus N` child (self-launched ranks for N > 1), the rows parsed
+    from the one JSON line each prints, the north_star table rendered -- rehearsed on CPU with two --selftest-cpu points
+    per series (no kernel runs; the rows say so)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    out_json = tmp_path / "sweep.json"
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "scale_sweep.py"), "--gpus", "1,2", "--selftest-cpu",
+                           "--steps", "3", "--warmup", "1", "--total-batch", "50", "--out", str(out_json)],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    res = json.loads(out_json.read_text())
+    rows = res["rows"]
+    assert [(r["series"].split()[0], r["n_gpus"]) for r in rows] == [("weak", 1), ("weak", 2), ("strong", 1), ("strong", 2)]
+    assert all(r.get("selftest") and r["clips_per_s"] > 0 and r["per_rank_min"] <= r["per_rank_max"] for r in rows)
+    assert rows[1]["scaling"] == "weak" and rows[3]["scaling"] == "strong"
+    table = proc.stdout
+    assert "| series | GPUs | clips/s |" in table and table.count("CPU self-test, no kernel") == 4

@@ -79,6 +79,32 @@ for _ in range(N): ctx.infer_i16(wav, lg, lb)
 ctx.sync(); dt_dev = time.perf_counter() - t1
 out["device_resident_clips_per_s"] = B * N / dt_dev
 out["labels_identical_across_routes"] = bool(np.array_equal(lab, lb.cpu().numpy()) and np.array_equal(lab_p, lab))
+# ---- many SMALL batches (the reference's own batch size is 1028, train.py:110): one synchronous kws_infer_host_i16 call per
+# batch (the pipeline fills and drains inside every call) against submit / wait with the next batch submitted before the
+# previous one is waited for (what KeywordSpotter.infer_batches does)
+small = {}
+for bs in (256, 1028, 4096):
+    nb = max(8, min(64, 65536 // bs))
+    batches = [clips[(i * bs) % (B - bs):(i * bs) % (B - bs) + bs] for i in range(nb)]
+    c2 = _native.Context(0)
+    c2.load_dscnn(blob, 12)
+    c2.infer_host_i16(batches[0])
+    t0 = time.perf_counter()
+    for b_ in batches:
+        c2.infer_host_i16(b_)
+    dt_sync = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pend = None
+    for b_ in batches:
+        nxt = c2.infer_host_submit_i16(b_)
+        if pend is not None:
+            c2.infer_host_wait(pend[2])
+        pend = nxt
+    c2.infer_host_wait(0)
+    dt_pipe = time.perf_counter() - t0
+    small[f"B={bs}"] = {"batches": nb, "one_call_per_batch_clips_per_s": bs * nb / dt_sync, "submit_wait_pipelined_clips_per_s": bs * nb / dt_pipe}
+    c2.close()
+out["small_batches"] = small
 best = max(v["clips_per_s"] for v in res.values())
 out["best_pageable_clips_per_s"] = best
 out["best_pageable_frac_of_raw_link"] = best * 32000 / 1e9 / max(out["raw_h2d_GBps_1_stream"], out["raw_h2d_GBps_2_stream"])
