@@ -240,6 +240,15 @@ int kws_stream_close(kws_ctx* ctx);
  * the counter) followed by the DS-CNN kernel.  use_graph != 0 replays the push as a hipGraph (built on first use for the
  * given pointer triple). */
 int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
+/* Shape of the one-launch push: workgroups per stream.  1: one workgroup owns a stream's whole DS-CNN (the layout of the
+ * batched kernel).  2 / 4: the stream's network is cut into that many TIME TILES, one workgroup each -- every stage's rows
+ * a tile's share of block 4's output depends on are recomputed inside the tile (about four rows of halo per side), nothing
+ * is exchanged between the workgroups but 64 pooled partial sums per tile at the very end, where the last workgroup to
+ * arrive adds them in tile order and runs fc + argmax.  At 64 streams one workgroup per stream leaves three quarters of the
+ * CUs idle and the push latency is one clip's serial path; four tiles bring the kernel from 37.6 to ~17 us.  0 (default):
+ * 4 up to 64 streams, 2 up to 128, else 1.  Logits of different shapes agree to the float32 rounding of the pooled sums
+ * (their order of addition differs); a given shape is deterministic. */
+int kws_stream_cluster(kws_ctx* ctx, int workgroups_per_stream);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
  * by the context) and the number of pushes so far; the newest frame is row (hops - K) mod num_frames, K = ceil(frame_len / frame_step)
  * hops per frame (3 for the reference's 400 / 160). */

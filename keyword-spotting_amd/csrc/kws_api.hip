@@ -865,6 +865,10 @@ static void stream_free(kws_ctx* c) {
     if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
     if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
     if (c->d_hops) (void)hipFree(c->d_hops);
+    if (c->d_cl_part) (void)hipFree(c->d_cl_part);
+    if (c->d_cl_count) (void)hipFree(c->d_cl_count);
+    c->d_cl_part = nullptr;
+    c->d_cl_count = nullptr;
     c->stream_graph = nullptr;
     c->d_pcm_ring = nullptr;
     c->d_feat_ring = nullptr;
@@ -887,7 +891,9 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     const size_t feat_b = sizeof(float) * (size_t)n_streams * p.num_frames * p.numcep;
     if (hipMalloc(reinterpret_cast<void**>(&c->d_pcm_ring), pcm_b) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&c->d_feat_ring), feat_b) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&c->d_hops), 2 * sizeof(int)) != hipSuccess) {
+        hipMalloc(reinterpret_cast<void**>(&c->d_hops), 2 * sizeof(int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_cl_part), sizeof(float) * (size_t)n_streams * 4 * 64) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_cl_count), sizeof(int) * (size_t)n_streams) != hipSuccess) {
         stream_free(c);
         return fail(c, KWS_ENOMEM, "kws_stream_open: device allocation failed");
     }
@@ -899,6 +905,19 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     HIP_TRY(c, hipMemsetAsync(c->d_pcm_ring, 0, pcm_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, 2 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_cl_count, 0, sizeof(int) * (size_t)n_streams, c->stream));
+    return KWS_OK;
+}
+
+int kws_stream_cluster(kws_ctx* c, int workgroups_per_stream) {
+    if (!c) return KWS_EINVAL;
+    if (workgroups_per_stream != 0 && workgroups_per_stream != 1 && workgroups_per_stream != 2 && workgroups_per_stream != 4)
+        return fail(c, KWS_EINVAL, "kws_stream_cluster: workgroups_per_stream must be 0 (automatic), 1, 2 or 4");
+    if (workgroups_per_stream != c->stream_cluster && c->stream_graph) {  // the captured graph holds the other launch shape
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        drop_stream_graph(c);
+    }
+    c->stream_cluster = workgroups_per_stream;
     return KWS_OK;
 }
 
@@ -1156,7 +1175,9 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         c->prof = was && timed;
         ProfScope ps(c, KWS_K_DSCNN);
         c->prof = was;
-        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine};
+        // time-tile clusters while there are CUs to spare: 4 workgroups per stream up to 64 streams, 2 up to 128 (256 CUs)
+        const int cluster = c->stream_cluster ? c->stream_cluster : (c->n_streams <= 64 ? 4 : (c->n_streams <= 128 ? 2 : 1));
+        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine, 0, cluster, c->d_cl_part, c->d_cl_count};
         return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label);
     }
     {

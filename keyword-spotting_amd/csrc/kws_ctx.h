@@ -56,6 +56,9 @@ struct kws_ctx {
     int16_t* d_pcm_ring = nullptr;
     float* d_feat_ring = nullptr;
     int* d_hops = nullptr;
+    int stream_cluster = 0;           // workgroups per stream of the fused push (kws_stream_cluster; 0 = by stream count)
+    float* d_cl_part = nullptr;       // [n_streams][4][64] pooled partial sums of a stream's time tiles
+    int* d_cl_count = nullptr;        // [n_streams]
     hipGraphExec_t stream_graph = nullptr;
     const void* graph_key[3] = {nullptr, nullptr, nullptr};
     // posterior smoothing history (kws_stream_smooth_f32): ring [n_streams][window][C], sum [n_streams][C], hop count

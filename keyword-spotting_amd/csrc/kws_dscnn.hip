@@ -247,12 +247,13 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 // k-block; the other tile's A fragments stream from L2 through a two-deep ring), wavefronts 4 and 5 take tile 4 for
 // one channel tile each, 6 and 7 have no conv1 work: one round, and the busiest SIMD (a dual and a single unit)
 // carries the matrix work of three single units but two split streams instead of three.
+// p_lo / p_hi: the positions this workgroup computes (the whole map, or the rows of one time tile: see PosRange).
 template <bool DUAL>
 __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const float* featp, float* z0, int ptile, int ct, int lane,
-                                                 const uintx4 (&c1f)[7][3]) {
+                                                 const uintx4 (&c1f)[7][3], int p_lo = 0, int p_hi = P0) {
     const int half = lane >> 5, col = lane & 31;
-    const int pos = ptile * 32 + col;
-    const int posc = pos < P0 ? pos : P0 - 1;
+    const int pos = p_lo + ptile * 32 + col;
+    const int posc = pos < p_hi ? pos : p_hi - 1;
     const int oh = posc / C1_W, ow = posc % C1_W;
     const float* base = featp + (2 * oh + 5 * half) * FEAT_W + 2 * ow;
     const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -326,7 +327,7 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
     }
     acc += acc2;
     occ += occ2;
-    if (pos < P0) {
+    if (pos < p_hi) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
             const int co = ct * 32 + row_of(r, half);
@@ -341,12 +342,25 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
     }
 }
 
-__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3]) {
+// Rows [lo, hi) of a map, as flattened positions [lo * W, hi * W): what one workgroup of a time-tile cluster computes of a
+// stage (the streaming push at few streams, see kws_dscnn_fwd_kernel).  The full map when the workgroup owns the clip.
+struct PosRange {
+    int lo, hi;
+};
+
+template <bool RANGED = false>
+__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3],
+                                                  PosRange rg = PosRange{0, P0}) {
     static_assert(P0 > 4 * 32 && P0 <= 5 * 32 && NW >= 6, "conv1 work split: four dual tiles + one tile in two halves");
     const float* featp = lds + OFF_FEAT;
     float* z0 = lds + OFF_Z0;
     const int lane = tid & 63, wv = tid >> 6;
-    if (wv < 4)
+    if constexpr (RANGED) {
+        // a time tile holds at most 4 position tiles of 32: one (tile, channel tile) unit per wavefront, one round -- the
+        // shortest critical path (a dual unit carries twice the matrix work); c1f holds channel tile wv & 1
+        const int n_pt = (rg.hi - rg.lo + 31) / 32;
+        for (int u = wv; u < 2 * n_pt; u += NW) conv1_unit_split<false>(w, featp, z0, u >> 1, u & 1, lane, c1f, rg.lo, rg.hi);
+    } else if (wv < 4)
         conv1_unit_split<true>(w, featp, z0, wv, wv & 1, lane, c1f);
     else if (wv < 6)
         conv1_unit_split<false>(w, featp, z0, 4, wv & 1, lane, c1f);
@@ -365,10 +379,13 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 // wrong results by construction).
 // act4 (diagnostics instantiation only, block 4): global [64][53*9] that receives the block's output, which the product
 // path never stores (it is pooled in registers).
-template <int N, int MODE>
+// RANGED: only the positions rg.lo .. rg.hi - 1 (whole rows) are computed -- one time tile of a workgroup cluster.
+template <int N, int MODE, bool RANGED = false>
 __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo,
-                                            float* __restrict__ act4 = nullptr) {
+                                            float* __restrict__ act4 = nullptr, PosRange rg = PosRange{0, 0}) {
     using G = Blk<N>;
+    const int p_lo = RANGED ? rg.lo : 0, p_hi = RANGED ? rg.hi : G::POUT;
+    const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : G::TILES;
     constexpr bool MFMA = MODE != 0;
     constexpr bool SPLIT = MODE >= 4;  // input channel of step s: 16(s>>3) + 8*half + (s&7) instead of 2s + half
     // timing ablation of the split path (wrong results by construction): 6 = split + matrix core without the stencil
@@ -403,11 +420,13 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) psum[ct][r] = 0.f;
 
-    for (int t = wv; t < G::TILES; t += NW) {
-        // column j of the tile is output position t*TW - 1 + j: columns 0 and 31 are halo
-        const int pos = t * TW - 1 + col;
-        const bool valid = col >= 1 && col <= TW && pos < G::POUT;
-        const int posc = pos < 0 ? 0 : (pos < G::POUT ? pos : G::POUT - 1);
+    for (int t = wv; t < n_tiles; t += NW) {
+        // column j of the tile is output position p_lo + t*TW - 1 + j: columns 0 and 31 are halo.  A halo column past the
+        // range's ends is clamped into it: a range ends on a row end, where the neighbour's contribution is masked anyway,
+        // and the clamp keeps the lane's own reads on rows this workgroup has computed.
+        const int pos = p_lo + t * TW - 1 + col;
+        const bool valid = col >= 1 && col <= TW && pos < p_hi;
+        const int posc = pos < p_lo ? p_lo : (pos < p_hi ? pos : p_hi - 1);
         const int h = posc / G::W, x = posc % G::W;
         const float mask_l = x > 0 ? 1.f : 0.f, mask_r = x < G::W - 1 ? 1.f : 0.f;
         // own-column tap addresses (rows h-1, h, h+1), as float indices into lds, for channel pairs
@@ -520,7 +539,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                         // this wave's next unit / of the next block
                         if (m < 3)
                             load_afrag(w, N, m + 1, lane, pwo.ring[(m + 1) & 1]);
-                        else if (t + NW < G::TILES)
+                        else if (t + NW < n_tiles)
                             load_afrag(w, N, 0, lane, pwo.ring[0]);
                         else if (N < 4)
                             load_afrag(w, N < 4 ? N + 1 : N, 0, lane, pwo.ring[0]);
@@ -609,7 +628,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             // this wave's last unit: the A operands are dead, so the next block's are fetched now and the
             // loads fly under the epilogue, the barrier and the next prologue
             if constexpr (!SPLIT) {
-                if (N < 4 && t + NW >= G::TILES) {
+                if (N < 4 && t + NW >= n_tiles) {
                     __builtin_amdgcn_sched_barrier(0);  // not before the last MFMA has read the old operands
                     if constexpr (N < 4) load_pointwise(w, N + 1, lane, pwo);
                     __builtin_amdgcn_sched_barrier(0);
@@ -658,7 +677,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
-            if (wv >= G::TILES) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
+            if (wv >= n_tiles) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
         } else {
             // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips).  Step-major:
             // all 32 sums take a shift step before any takes the next, so a value is read by DPP well after it was written and
@@ -769,13 +788,21 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 // STREAM: the streaming push in one launch (launch_dscnn_stream).  `feat` is the feature ring (its newest row is written
 // here, through a pointer derived from `feat`, and never read), wavefront 0 computes the stream's new frame straight into the LDS feature map while the other
 // wavefronts fetch the 98 older rows, and the hop counter sp.hops advances when the last workgroup is done.
-template <int MODE, bool DIAG = true, bool PRECONV = false, bool STREAM = false>
+// CLUSTER (with STREAM): sp.cluster workgroups share one stream's network by TIME TILES -- at 64 streams one workgroup per
+// stream leaves three quarters of the CUs idle and the push latency is one clip's serial path through the kernel.  Workgroup
+// (stream, tile) computes the rows of block 4's output that belong to its tile and, of every earlier stage, the rows those
+// depend on (one more row per side and stage: ~4 conv1 rows of halo per side, recomputed, no exchange between workgroups);
+// everything stays LDS-resident per tile.  Only the LAST tile needs the window's newest row, so only its wavefront 0 runs
+// the one-frame front end.  The tiles' pooled partial sums meet in global memory; the workgroup that arrives last (a
+// counter per stream) adds them in tile order, adds the ring term and runs fc + argmax.
+template <int MODE, bool DIAG = true, bool PRECONV = false, bool STREAM = false, bool CLUSTER = false>
 __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const float* __restrict__ feat, int B,
                                                            float* __restrict__ logits, int32_t* __restrict__ label,
                                                            float* __restrict__ act_arg,
                                                            unsigned long long* __restrict__ stamps_arg,
                                                            const int* __restrict__ ring_hops, StreamPush sp) {
     static_assert(!STREAM || (MODE >= 4 && !DIAG && !PRECONV), "the fused push exists for the product path only");
+    static_assert(!CLUSTER || STREAM, "time-tile clusters exist for the streaming push only");
     float* const act = DIAG ? act_arg : nullptr;
     unsigned long long* const stamps = DIAG ? stamps_arg : nullptr;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -785,8 +812,18 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     // One clip per workgroup (no persistent loop: hoisting the ~400 weight addresses out of a clip
     // loop costs more registers than the relaunch saves).
-    const int clip = blockIdx.x;
+    const int cl_n = CLUSTER ? sp.cluster : 1;
+    const int clip = CLUSTER ? (int)blockIdx.x / cl_n : (int)blockIdx.x;
+    const int cl_tile = CLUSTER ? (int)blockIdx.x - clip * cl_n : 0;
     if (clip >= B) return;
+    // Rows of each stage this workgroup computes (CLUSTER; otherwise everything).  Block 4's output rows [j0, j1) need block
+    // 3's rows [j0 - 2, j1) (a 3-row stencil, and block 3's stored plane is block 4's input without its ring: row index - 1),
+    // those need block 2's [j0 - 4, j1), block 1's [j0 - 6, j1), and block 1 reads conv1's rows [j0 - 7, j1 + 1) (no ring there).
+    const int j0 = Blk<4>::H * cl_tile / cl_n, j1 = Blk<4>::H * (cl_tile + 1) / cl_n;
+    auto rows = [&](int lo, int hi, int H, int W) { return PosRange{(lo < 0 ? 0 : lo) * W, (hi > H ? H : hi) * W}; };
+    const PosRange rg4 = rows(j0, j1, Blk<4>::H, Blk<4>::W), rg3 = rows(j0 - 2, j1, Blk<3>::H, Blk<3>::W),
+                   rg2 = rows(j0 - 4, j1, Blk<2>::H, Blk<2>::W), rg1 = rows(j0 - 6, j1, Blk<1>::H, Blk<1>::W),
+                   rg0 = rows(j0 - 7, j1 + 1, C1_H, C1_W);
     // diagnostics only (stamps == nullptr in every product call): shader-clock stamps of thread 0 at the
     // phase boundaries, KWS_DSCNN_STAMPS per clip; [14] and [15] carry the 100 MHz real-time counter
     int n_stamp = 0;
@@ -864,7 +901,11 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         // One barrier: the zero fill touches only the padding, the scatter only the interior, and the new frame's row is
         // written by wavefront 0 alone, straight from the cepstrum registers of its one-frame front end (scratch and tables
         // in the region block 2 will overwrite much later).
-        if (wv == 0)  // first: its sample and table loads join the feature loads already in flight
+#ifdef KWS_X_STREAM_NO_FRAME  // timing experiment (wrong results): the push without the one-frame front end on any tile's path
+        if (false)
+#else
+        if (wv == 0 && cl_tile == cl_n - 1)  // first: its sample and table loads join the feature loads already in flight
+#endif
             stream_frame_wave(sp.p, sp.t, sp.hop, clip, clip, false, sp.pcm_ring, sp.ring_len, const_cast<float*>(feat), hops_before,
                               reinterpret_cast<unsigned char*>(lds + OFF_Z2), lane,
                               row_new >= 0 ? featp + (row_new + 2) * FEAT_W + 2 : nullptr, sp.refine_ctr);
@@ -893,7 +934,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     stamp();  // 1: features staged
 
     if constexpr (SPLIT) {
-        conv1_phase_split(w, lds, tid, c1f);
+        conv1_phase_split<CLUSTER>(w, lds, tid, c1f, rg0);
         load_block_head(w, 1, lane, wa);  // the conv1 operands are dead: block 1's first fly across the barrier
     } else {
         conv1_phase<MFMA>(w, lds, tid, a1);
@@ -908,7 +949,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         a += CH * P0;
     }
 
-    block_phase<1, MODE>(w, lds, tid, wa);
+    block_phase<1, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg1);
     stamp();  // 4: block 1 units of wave 0 done
     __syncthreads();
     stamp();  // 5: block 1 barrier
@@ -917,7 +958,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z1 + pidx(i / Blk<1>::POUT, i % Blk<1>::POUT, Blk<1>::SOUT)];
         a += CH * Blk<1>::POUT;
     }
-    block_phase<2, MODE>(w, lds, tid, wa);
+    block_phase<2, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg2);
     stamp();  // 6
     __syncthreads();
     stamp();  // 7
@@ -926,7 +967,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z2 + pidx(i / Blk<2>::POUT, i % Blk<2>::POUT, Blk<2>::SOUT)];
         a += CH * Blk<2>::POUT;
     }
-    block_phase<3, MODE>(w, lds, tid, wa);
+    block_phase<3, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg3);
     stamp();  // 8
     __syncthreads();
     stamp();  // 9
@@ -935,7 +976,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             a[i] = lds[OFF_Z3 + pidx(i / Blk<3>::POUT, i % Blk<3>::POUT, Blk<3>::SOUT)];
         a += CH * Blk<3>::POUT;
     }
-    block_phase<4, MODE>(w, lds, tid, wa, a ? a + CH : nullptr);  // block 4's output follows the pooled means
+    block_phase<4, MODE, CLUSTER>(w, lds, tid, wa, a ? a + CH : nullptr, rg4);  // block 4's output follows the pooled means
     stamp();  // 10
     // The classifier row of lane c (wavefront 0) and the ring bias of channel tid are requested BEFORE the barrier:
     // their L2 round trips pass while the workgroup waits for its slowest wavefront, instead of sitting exposed at
@@ -955,19 +996,55 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     // ---- global average pool over 55 x 11 = 477 interior + 128 ring positions ---------------------
     float* pooled = lds + OFF_POOLED;
+    constexpr float RING_N = 55.f * 11.f - 53.f * 9.f;  // 128
+    bool run_fc = true;  // workgroup-uniform
+    if constexpr (CLUSTER) {
+        // this tile's partial sums go to global memory (agent-scope stores: the other tiles' workgroups sit on other XCDs, whose
+        // L2s are not coherent with this one); the workgroup of the stream that arrives last combines them in tile order
+        float* part = sp.cl_part + ((size_t)clip * cl_n + cl_tile) * CH;
+        if (tid < CH) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) s += lds[OFF_POOLBUF + k * CH + tid];
+            __hip_atomic_store(part + tid, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // No fence: an agent-scope release writes the XCD's whole L2 back -- measured 0.33 us per workgroup, serialised
+        // across the chip (256 workgroups: 88 us).  The partial sums are agent-scope atomic stores (write-through to the
+        // coherence point); once they are acknowledged (vmcnt 0) any XCD's agent-scope load sees them, and the counter is
+        // bumped only after the whole workgroup has passed that wait.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* last_flag = reinterpret_cast<int*>(lds + OFF_POOLED + CH);
+        if (tid == 0) {
+            const int arrived = atomicAdd(&sp.cl_count[clip], 1);
+            *last_flag = arrived == cl_n - 1;
+            if (arrived == cl_n - 1) sp.cl_count[clip] = 0;  // for the next push (published by the kernel boundary)
+        }
+        __syncthreads();
+        run_fc = *last_flag != 0;
+        if (run_fc) {
+            if (tid < CH) {  // agent-scope loads: never served from this XCD's (non-coherent) L2
+                float s = 0.f;
+                for (int t = 0; t < cl_n; ++t)
+                    s += __hip_atomic_load(sp.cl_part + ((size_t)clip * cl_n + t) * CH + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pooled[tid] = fmaf(RING_N, relu(ring_b), s) * (1.0f / (55.f * 11.f));
+            }
+        }
+        __syncthreads();
+    } else {
     if (tid < CH) {
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) s += lds[OFF_POOLBUF + k * CH + tid];
-        constexpr float RING_N = 55.f * 11.f - 53.f * 9.f;  // 128
         s = fmaf(RING_N, relu(ring_b), s) * (1.0f / (55.f * 11.f));
         pooled[tid] = s;
         if (a) a[tid] = s;
     }
     __syncthreads();
+    }
 
     // ---- Linear(64 -> C) + argmax (first maximum wins) on wavefront 0 ------------------------------
-    if (wv == 0) {
+    if (run_fc && wv == 0) {
         float v = -INFINITY;
         if (lane < C) {
             float acc = fcb;
@@ -1019,7 +1096,8 @@ hipError_t dscnn_init_device() {
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<6>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, true>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true, true>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -1076,9 +1154,13 @@ hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in
 
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
                                float* d_logits, int32_t* d_label) {
-    static_assert(sizeof(float) * (size_t)(LDS_FLOATS - OFF_Z2) >= 16 * 1024, "room for the one-frame front end's tables and scratch");
-    hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true>), dim3(n_streams), dim3(NT), LDS_FLOATS * sizeof(float), s, w,
-                       d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+    static_assert(sizeof(float) * (size_t)(LDS_FLOATS - OFF_Z2) >= 16 * 1024 + STREAM_F64_BYTES, "room for the one-frame front end's tables and scratch");
+    if (sp.cluster > 1)
+        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true, true>), dim3(n_streams * sp.cluster), dim3(NT), LDS_FLOATS * sizeof(float),
+                           s, w, d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+    else
+        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true>), dim3(n_streams), dim3(NT), LDS_FLOATS * sizeof(float), s, w,
+                           d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
     return hipGetLastError();
 }
 

@@ -165,6 +165,9 @@ struct StreamPush {
     int* hops;
     int* refine_ctr;         // counters of the selective refinement (RefineList::ctr; [5] counts frames redone by pushes) or NULL
     int frames_lag;          // two-launch route only: hops a frame spans, ceil(frame_len / frame_step) (the fused push derives it from p)
+    int cluster;             // workgroups per stream of the fused push (time tiles; 1 = one workgroup owns the stream's network)
+    float* cl_part;          // [n_streams][cluster][64] pooled partial sums of the tiles
+    int* cl_count;           // [n_streams] tiles that have delivered theirs (the last one runs fc + argmax and clears it)
 };
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
                                float* d_logits, int32_t* d_label);

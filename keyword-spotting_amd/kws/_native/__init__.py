@@ -64,6 +64,7 @@ SIGNATURES = {
     "kws_forward_debug_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p, _f32p, C.c_int]),
     "kws_stream_open": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_close": (C.c_int, [_c_ctx]),
+    "kws_stream_cluster": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_push_i16": (C.c_int, [_c_ctx, _i16p, _f32p, _i32p, C.c_int]),
     "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
@@ -324,6 +325,10 @@ class Context:
     # -- streaming -------------------------------------------------------------------------------
     def stream_open(self, n_streams: int):
         self._check(self._lib.kws_stream_open(self._h, int(n_streams)), AudioProcessingError)
+
+    def stream_cluster(self, workgroups_per_stream: int = 0):
+        """Workgroups per stream of the one-launch push: 1, or 2 / 4 time tiles; 0 = by stream count (``kws_stream_cluster``)."""
+        self._check(self._lib.kws_stream_cluster(self._h, int(workgroups_per_stream)), ModelError)
 
     def stream_close(self):
         self._check(self._lib.kws_stream_close(self._h))

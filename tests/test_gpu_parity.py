@@ -1435,6 +1435,7 @@ def test_streaming_full_size_64_and_257_streams(dev, e2e_golden, use_graph):
     for S in (257, 64, 1):
         src = pcm[:S] if S > 1 else pcm[256:257]
         sp = StreamingSpotter(S, model, use_graph=use_graph)
+        sp._ctx.stream_cluster(1)   # one launch shape for all three runs: bit-for-bit independence is a statement about one shape
         try:
             for t in range(hops):
                 labels, logits = sp.push(src[:, t * 160:(t + 1) * 160])
@@ -1457,6 +1458,61 @@ def test_streaming_full_size_64_and_257_streams(dev, e2e_golden, use_graph):
         assert err <= TOL, (s, err)
         assert_labels_match(y257[s:s + 1], ref, err)
     assert len(np.unique(y257)) >= 3 and float(l257.std(axis=0).mean()) >= 0.1
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_streaming_time_tile_clusters_agree(native, dev, e2e_golden, use_graph):
+    """The one-launch push at 64 streams as 4, 2 and 1 workgroups per stream (time tiles with recomputed halos; the tiles'
+    pooled partial sums meet in global memory and the last workgroup to arrive runs fc + argmax).  Same feature rings bit for
+    bit; logits within 2e-5 of their scale (only the order in which the pooled sums are added differs: per wavefront, then
+    per tile) and within 1e-4 of the oracle for every shape; labels identical; a shape is deterministic run to run; the
+    automatic choice is 4 tiles at 64 streams.  Across the ring wrap (hop > 99), with a silent and a fading stream."""
+    from kws.inference import StreamingSpotter
+
+    S, hops = 64, 118
+    model = he_model(e2e_golden)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(61)
+    pcm = rng.integers(-20000, 20000, size=(S, hops * 160), dtype=np.int16)
+    pcm = np.round(pcm * (rng.uniform(0.0, 1.0, S) ** 3)[:, None]).astype(np.int16)
+    pcm[3] = 0
+    pcm[9] = (pcm[9] * np.linspace(0.0, 1.0, hops * 160)).astype(np.int16)
+    pcm[11] = np.round(7000 * np.sin(2 * np.pi * 900 * np.arange(hops * 160) / 16000.0)).astype(np.int16)
+    runs = {}
+    for shape in (0, 4, 2, 1, 4):           # 0 = automatic; the second "4" checks determinism
+        sp = StreamingSpotter(S, model, use_graph=use_graph)
+        try:
+            sp._ctx.stream_cluster(shape)
+            checks = []
+            for t in range(hops):
+                labels, logits = sp.push(pcm[:, t * 160:(t + 1) * 160])
+                if t in (2, 40, 98, 99, 100, hops - 1):
+                    checks.append((labels.copy(), logits.copy()))
+            feats, pushed = sp.features()
+            assert pushed == hops
+            runs.setdefault(shape, []).append((checks, feats))
+        finally:
+            sp.close()
+    base_checks, base_feats = runs[1][0]
+    newest = hops - 3
+    want = np.zeros((S, 99, 10), np.float32)
+    for s_ in range(S):
+        allf = o_mfcc.mfcc(o_mfcc.pcm16_to_float(pcm[s_]), o_mfcc.FrontendSpec(n_samples=pcm.shape[1]))
+        want[s_] = allf[newest - 98:newest + 1]
+    ref = o_dscnn.forward(state, torch.from_numpy(want)[:, None])
+    for shape, lst in runs.items():
+        for checks, feats in lst:
+            assert np.array_equal(feats, base_feats), shape
+            for (lab, lg), (lab1, lg1) in zip(checks, base_checks):
+                assert np.abs(lg - lg1).max() <= 2e-5 * max(1.0, float(np.abs(lg1).max())), shape
+                assert np.array_equal(lab, lab1), shape
+            err = float(np.abs(checks[-1][1] - ref.numpy()).max())
+            assert err <= TOL, (shape, err)
+            assert_labels_match(checks[-1][0], ref, err)
+    assert np.abs(base_feats - want).max() <= TOL
+    a, b = runs[4]
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(a[0], b[0]))                      # deterministic
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(runs[0][0][0], a[0]))             # automatic == 4 tiles at 64 streams
 
 
 def test_infer_files_of_any_wav_encoding(dev, tmp_path, e2e_golden):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5: 64 concurrent streams, 10 ms hops, per-hop latency on one MI355X.
 
-    python tools/bench_stream.py [n_streams] [hops] [eager|hipgraph|both]
+    python tools/bench_stream.py [n_streams] [hops] [eager|hipgraph|both] [workgroups per stream: 0 = automatic, 1, 2, 4]
 
 A hop = 160 new int16 samples per stream already resident in device memory; latency = host wall time from
 kws_stream_push_i16 to the labels being complete (kws_sync), i.e. launch + frame kernel + hop counter +
@@ -21,11 +21,12 @@ import bench
 from kws import _native
 
 
-def run(S, hops, use_graph):
+def run(S, hops, use_graph, cluster=0):
     dev = torch.device("cuda", 0)
     ctx = _native.Context(0)
     ctx.load_dscnn(bench.bench_weights()[0], 12)
     ctx.stream_open(S)
+    ctx.stream_cluster(cluster)
     pcm = torch.from_numpy(np.random.default_rng(0).integers(-32768, 32768, size=(hops, S, 160), dtype=np.int16)).to(dev)
     hop = torch.empty((S, 160), dtype=torch.int16, device=dev)
     logits = torch.empty((S, 12), dtype=torch.float32, device=dev)
@@ -38,21 +39,34 @@ def run(S, hops, use_graph):
         ctx.stream_push_i16(hop, logits, labels, use_graph=use_graph)
         ctx.sync()
         lat.append((time.perf_counter() - t0) * 1e6)
+    kern = None
+    if not use_graph:  # the kernel's own duration (HIP events on the stream), 60 more pushes
+        ctx.prof_enable(1); ctx.prof_reset()
+        for t in range(60):
+            hop.copy_(pcm[t]); torch.cuda.synchronize()
+            ctx.stream_push_i16(hop, logits, labels)
+        ms, n = ctx.prof_read(_native.KWS_K_DSCNN)
+        kern = ms / max(n, 1) * 1e3
+        ctx.prof_enable(0)
     ctx.stream_close(); ctx.close()
     lat = np.array(lat[min(20, len(lat) // 4):])  # drop warm-up (graph build, clocks)
-    return {"p50_us": float(np.percentile(lat, 50)), "p90_us": float(np.percentile(lat, 90)), "p99_us": float(np.percentile(lat, 99)),
-            "mean_us": float(lat.mean()), "hops_timed": int(len(lat))}
+    out = {"p50_us": float(np.percentile(lat, 50)), "p90_us": float(np.percentile(lat, 90)), "p99_us": float(np.percentile(lat, 99)),
+           "mean_us": float(lat.mean()), "hops_timed": int(len(lat)), "workgroups_per_stream": cluster}
+    if kern is not None:
+        out["kernel_us"] = kern
+    return out
 
 
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     hops = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     which = sys.argv[3] if len(sys.argv) > 3 else "both"   # one mode only: exactly `hops` launches per kernel (profiles)
+    cluster = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     out = {"config": f"C5: {S} concurrent streams, 10 ms hop (160 samples @ 16 kHz), MFCC frame + DS-CNN over the last 99 frames per hop"}
     if which in ("eager", "both"):
-        out["eager"] = run(S, hops, False)
+        out["eager"] = run(S, hops, False, cluster)
     if which in ("hipgraph", "both"):
-        out["hipgraph"] = run(S, hops, True)
+        out["hipgraph"] = run(S, hops, True, cluster)
     out["real_time_factor_p50"] = 10000.0 / min(v["p50_us"] for k, v in out.items() if k in ("eager", "hipgraph"))
     print(json.dumps(out))
 
