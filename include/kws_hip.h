@@ -237,8 +237,9 @@ int kws_stream_close(kws_ctx* ctx);
  * d_label int32 [n_streams] or NULL.  With logits and the default pointwise math a push is ONE launch: each stream's
  * workgroup of the DS-CNN kernel computes the stream's new frame in its prologue and the last workgroup advances the hop
  * counter.  Features-only pushes, and pushes under KWS_PW_F32 / the VALU check, are the frame kernel (which then advances
- * the counter) followed by the DS-CNN kernel.  use_graph != 0 replays the push as a hipGraph (built on first use for the
- * given pointer triple). */
+ * the counter) followed by the DS-CNN kernel.  use_graph != 0 replays a MULTI-launch push as a hipGraph (built on first use
+ * for the given pointer triple); the one-launch push is always launched directly -- a one-node graph replay is 8 us slower
+ * than the plain launch on this stack (tools/graph_overhead.hip). */
 int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int32_t* d_label, int use_graph);
 /* Shape of the one-launch push: workgroups per stream.  1: one workgroup owns a stream's whole DS-CNN (the layout of the
  * batched kernel).  2 / 4: the stream's network is cut into that many TIME TILES, one workgroup each -- every stage's rows

@@ -1211,6 +1211,11 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
             return fail(c, KWS_EUNSUPPORTED, "kws_stream_push_i16: the DS-CNN kernel is built for a 99 x 10 feature map");
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    // A push that is ONE kernel launch gains nothing from a graph -- on this stack it loses: hipGraphLaunch of a one-node graph
+    // takes 6.9 us of host time against 3.0 us for the plain launch, and completion is observed 8 us later in all
+    // (tools/graph_overhead.hip: 20.6 vs 12.3 us launch -> hipStreamSynchronize for a trivial kernel; still 23.6 vs 20.3 us at
+    // four kernels).  use_graph is honoured for the multi-launch routes only, where it saves host time per push.
+    if (use_graph && d_logits && c->pw_math == KWS_PW_SPLIT_BF16) use_graph = 0;
     if (use_graph) {
         // one hipGraph per (hop, logits, label) pointer triple: the two launches replay as one submission
         if (!c->stream_graph || c->graph_key[0] != d_hop || c->graph_key[1] != d_logits || c->graph_key[2] != d_label) {

@@ -22,6 +22,8 @@
 // Numerics: PCM/32768 and pre-emphasis are bit-exact float32 as in the reference pipeline (separate
 // multiply and subtract roundings); everything after is float32 here vs float64 in psf
 // (tolerance 1e-4 on MFCC, see tests/test_gpu_parity.py).
+#include <cstdlib>
+
 #include "kws_internal.h"
 #include "kws_mfcc_dev.h"
 
@@ -167,9 +169,10 @@ __device__ __forceinline__ void mfcc_body(const FrontendParams& p, const Fronten
 #endif
 // amdgpu_waves_per_eu(4, 4): 128 registers, so that the four 4-wave workgroups the LDS admits per CU (16
 // wavefronts, 4 per SIMD) all become resident; the kernel is latency-bound on LDS round trips.
-// kws_mfcc_{i16,f32}_kernel: frame lengths in (384, 448] (the reference's 400 samples), see TAIL6; the *_any_kernel pair
-// takes every other frame length up to 512 (one kernel with both bodies spills registers).
-__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_kernel(FrontendParams p, FrontendTables t,
+// kws_mfcc_i16_tile_kernel / kws_mfcc_f32_kernel: frame lengths in (384, 448] (the reference's 400 samples), see TAIL6; the
+// *_any_kernel pair takes every other frame length up to 512 (one kernel with both bodies spills registers).  int16 input
+// at a geometry the wavefront-resident kernel below covers goes there instead (kws_mfcc_i16_kernel, the product path).
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_tile_kernel(FrontendParams p, FrontendTables t,
                                                                     const int16_t* __restrict__ wav,
                                                                     float* __restrict__ out, RefineList rl) {
     mfcc_body<int16_t, true>(p, t, wav, out, rl);
@@ -188,6 +191,160 @@ __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KW
                                                                     const float* __restrict__ wav,
                                                                     float* __restrict__ out, RefineList rl) {
     mfcc_body<float, false>(p, t, wav, out, rl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The product kernel for int16 PCM at the reference geometry (round 3): WAVEFRONT-RESIDENT runs of a clip.
+//
+// The tile kernel above pays, for every 12 frame pairs, a workgroup launch, ~40 table loads per lane, a scratch clear, the
+// global-memory latency of its PCM span and a workgroup barrier, and its four wavefronts march in step.  Here a wavefront
+// owns a run of a clip's chunks (five by default: 20 frames) for its whole lifetime: tables and per-lane constants are
+// loaded once, then it walks its run in chunks of four frames (two packed pairs).  A chunk's PCM span (3 steps + one frame
+// = 880 samples) arrives as two 16-byte loads per lane, is converted and pre-emphasised in registers (the sample before a
+// lane's vector comes from its neighbour by DPP) and lands in the wavefront's own 4 KB of LDS.  No wavefront ever waits for
+// another: the one __syncthreads publishes the shared DCT and twiddle tables at the start.  Consecutive spans overlap by
+// 240 samples; the re-read is an L2 hit issued by the same wavefront a few microseconds earlier.  Same arithmetic, same
+// bits as the tile kernel (PCM scaling and pre-emphasis are the same two float32 roundings; mfcc_pair is shared).
+// Measured on 4096 clips, same box and call: tile kernel 0.208 ms, this kernel 0.183 ms.  (Issuing the next chunk's loads
+// before this chunk's transforms -- a register prefetch -- was measured and dropped: the eight vector registers it keeps
+// alive spill under the 128-register cap, 0.201 ms; the other three wavefronts of the SIMD cover the latency.)
+constexpr int WR_PAIRS = 2, WR_FRAMES = 2 * WR_PAIRS;   // frames per chunk
+constexpr int WR_SPAN = 1024;                            // floats of LDS per wavefront for the chunk's span (two uint4 of PCM per lane)
+constexpr int WR_WAVE_BYTES = WR_SPAN * 4 + SCR_BYTES;
+
+__host__ __device__ inline size_t mfcc_wr_lds_bytes(const FrontendParams& p) {
+    const int nfp = (p.nfilt + 3) & ~3;
+    return sizeof(float) * (size_t)(((p.numcep * nfp + 3) & ~3) + 2 * 64) + (size_t)MFCC_WAVES * WR_WAVE_BYTES;
+}
+
+__global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KWS_MFCC_EU, KWS_MFCC_EU))) void kws_mfcc_i16_kernel(
+    FrontendParams p, FrontendTables t, const int16_t* __restrict__ wav, float* __restrict__ out, RefineList rl, int B, int chunks_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nfp = (p.nfilt + 3) & ~3;
+    float* dctb = reinterpret_cast<float*>(smem);
+    cf* tw2 = reinterpret_cast<cf*>(dctb + ((p.numcep * nfp + 3) & ~3));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned char* mine = reinterpret_cast<unsigned char*>(tw2 + 64) + wv * WR_WAVE_BYTES;
+    float* ybuf = reinterpret_cast<float*>(mine);
+    unsigned char* scr = mine + WR_SPAN * 4;
+
+    for (int i = tid; i < (p.numcep * nfp + 3) / 4; i += MFCC_THREADS)
+        reinterpret_cast<float4*>(dctb)[i] = reinterpret_cast<const float4*>(t.dct_pad)[i];
+    fill_tw2(t.twiddle, tw2, tid);
+    cf t1[8];
+    load_twiddles(t.twiddle, lane, t1);
+    MelLane ml;
+    load_mel_lane(t, lane, ml);
+    zero_scratch(scr, lane);
+
+    // this wavefront's share: chunks [c, c_end) of clip `clip`
+    const int n_chunks = (p.num_frames + WR_FRAMES - 1) / WR_FRAMES;
+    const int waves_per_clip = (n_chunks + chunks_per_wave - 1) / chunks_per_wave;
+    const int gw = blockIdx.x * MFCC_WAVES + wv;
+    const int clip = gw / waves_per_clip, part = gw - clip * waves_per_clip;
+    int c = part * chunks_per_wave;
+    const int c_end = min(n_chunks, c + chunks_per_wave);
+    const bool active = clip < B && c < c_end;  // wave-uniform
+    const int16_t* __restrict__ x = wav + (size_t)(active ? clip : 0) * p.n_samples;
+    const int chunk_step = WR_FRAMES * p.frame_step;  // samples from one chunk's span to the next (a multiple of 8: checked by the launcher)
+
+    // two 16-byte vectors of PCM per lane cover the span; a vector is inside the clip or past its end (n_samples % 8 == 0)
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+    int16_t before = 0;
+    auto fetch = [&](int cc) {
+        const int s0 = cc * chunk_step;
+        const int n0 = s0 + 8 * lane, n1 = n0 + 512;
+        v0 = n0 + 8 <= p.n_samples ? *reinterpret_cast<const uint4*>(x + n0) : make_uint4(0, 0, 0, 0);
+        v1 = n1 + 8 <= p.n_samples ? *reinterpret_cast<const uint4*>(x + n1) : make_uint4(0, 0, 0, 0);
+        before = s0 > 0 ? x[s0 - 1] : (int16_t)0;
+    };
+#ifdef KWS_X_MFCC_PREFETCH
+    if (active) fetch(c);
+#endif
+    __syncthreads();  // the only workgroup barrier: the shared tables are in place
+    if (!active) return;
+
+    const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
+                            reinterpret_cast<float*>(scr + SCR_LBUF), dctb, tw2, nfp};
+    const float pre = p.preemph;
+    for (; c < c_end; ++c) {
+#ifndef KWS_X_MFCC_PREFETCH
+        fetch(c);
+#endif
+        // ---- registers -> float32, pre-emphasised, into this wavefront's span buffer -----------------------
+        {
+            const int s0 = c * chunk_step;
+            // the sample before a lane's vector: the last half-word of the neighbouring lane's vector (wave_shr:1), of lane 63's
+            // first vector for lane 0's second, of the clip for lane 0's first
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v0.w, 0x138, 0xf, 0xf, false);
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1.w, 0x138, 0xf, 0xf, false);
+            const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)v0.w, 63);
+            float prev0 = lane == 0 ? to_unit(before) : to_unit((int16_t)(w0 >> 16));
+            float prev1 = lane == 0 ? to_unit((int16_t)(last0 >> 16)) : to_unit((int16_t)(w1 >> 16));
+            auto convert = [&](const uint4& raw, float prev, int n, float* dst) {
+                const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float cur = to_unit((int16_t)((wd[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+                    y[i] = __fsub_rn(cur, __fmul_rn(pre, prev));
+                    prev = cur;
+                }
+                if (n == 0) y[0] = to_unit((int16_t)(wd[0] & 0xffffu));  // the clip's first sample is not pre-emphasised
+                if (n + 8 > p.n_samples) {                                 // past the clip: psf pads the PRE-EMPHASISED signal with zeros
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = 0.f;
+                }
+                reinterpret_cast<float4*>(dst)[0] = make_float4(y[0], y[1], y[2], y[3]);
+                reinterpret_cast<float4*>(dst)[1] = make_float4(y[4], y[5], y[6], y[7]);
+            };
+            convert(v0, prev0, s0 + 8 * lane, ybuf + 8 * lane);
+            convert(v1, prev1, s0 + 512 + 8 * lane, ybuf + 512 + 8 * lane);
+        }
+        wave_lds_order();
+#ifdef KWS_X_MFCC_PREFETCH  // (experiment, see the header comment: the prefetched vectors spill under the 128-register cap)
+        if (c + 1 < c_end) fetch(c + 1);
+#endif
+#pragma unroll 1
+        for (int pr = 0; pr < WR_PAIRS; ++pr) {
+            const int fa = WR_FRAMES * c + 2 * pr;
+            if (fa >= p.num_frames) break;  // wave-uniform
+            const bool has_b = fa + 1 < p.num_frames;
+            const float* ya = ybuf + (2 * pr) * p.frame_step;
+            const float* yb = ya + p.frame_step;
+            cf v[8];
+            uint32_t ora = 0u, orb = 0u;
+#pragma unroll
+            for (int n1 = 0; n1 < 7; ++n1) {  // frame_len in (384, 448]: block 6 is cut by a lane bound, block 7 is zero
+                const int i = 64 * n1 + lane;
+                float a = ya[i], b = yb[i];
+                if (n1 == 6) {
+                    const bool in = i < p.frame_len;
+                    a = in ? a : 0.f, b = in ? b : 0.f;
+                }
+                v[n1] = cf{a, b};
+                ora |= __builtin_bit_cast(uint32_t, a);
+                orb |= __builtin_bit_cast(uint32_t, b);
+            }
+            v[7] = cf{0.f, 0.f};
+            if (!has_b) {  // the clip's last pair only: frame b is past the clip
+#pragma unroll
+                for (int n1 = 0; n1 < 7; ++n1) v[n1].y = 0.f;
+                orb = 0u;
+            }
+            const bool nza = __any((ora << 1) != 0u);
+            const bool nzb = __any((orb << 1) != 0u);
+            const uint32_t flags = mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
+                                             out + ((size_t)clip * p.num_frames + fa) * p.numcep,
+                                             out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
+            if (flags && rl.ctr && lane == 0) {  // (see the tile kernel)
+                const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(rl.ctr), 1ull | ((unsigned long long)__builtin_popcount(flags) << 32));
+                const int at = (int)(unsigned)old;
+                if (at < rl.cap) rl.list[at] = (int)((((unsigned)(rl.clip0 + clip) * (unsigned)((p.num_frames + 1) / 2) + (unsigned)(fa >> 1)) << 2) | flags);
+            }
+            wave_lds_order();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -332,7 +489,34 @@ static hipError_t launch_mfcc_t(K kernel, hipStream_t s, const FrontendParams& p
 hipError_t launch_mfcc_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B,
                             float* d_out, const RefineList& rl) {
     const bool tail6 = p.frame_len > 384 && p.frame_len <= 448;
-    return launch_mfcc_t(tail6 ? kws_mfcc_i16_kernel : kws_mfcc_i16_any_kernel, s, p, t, d_wav, B, d_out, rl);
+#ifndef KWS_X_MFCC_TILE_KERNEL  // (A/B switch: the round-2 tile kernel for every geometry)
+    // the wavefront-resident kernel: 16-byte PCM vectors (aligned clips and chunk starts), a chunk's span within two vectors per lane
+    if (tail6 && p.vec_ok && (WR_FRAMES * p.frame_step) % 8 == 0 && (WR_FRAMES - 1) * p.frame_step + 448 <= WR_SPAN) {
+        const size_t lds = mfcc_wr_lds_bytes(p);
+        const int n_chunks = (p.num_frames + WR_FRAMES - 1) / WR_FRAMES;
+        for (int b0 = 0; b0 < B; b0 += (1 << 20)) {  // (grid.x limit: 2^31 workgroups; a million clips per launch keeps indices in 32 bits)
+            const int nb = B - b0 < (1 << 20) ? B - b0 : (1 << 20);
+            // ~5 chunks (20 frames) per wavefront, split evenly (99 frames = 25 chunks = 5 x 5): measured on 4096 clips, 1 / 5 / 25
+            // chunks per wavefront take 0.219 / 0.183 / 0.201 ms -- short-lived wavefronts keep the CUs' phases mixed and the tail
+            // short, an uneven split (6 + 6 + 6 + 6 + 1: 0.209 ms) wastes a wavefront's set-up on one chunk.  Small batches spread
+            // a clip over more wavefronts, down to one chunk each, so that even one clip uses 25 wavefronts.
+            int wpc = (n_chunks + 2) / 5;
+            wpc = wpc < 1 ? 1 : wpc;
+            int cpw = (n_chunks + wpc - 1) / wpc;
+            const int fill = (int)(((long)nb * n_chunks + 4095) / 4096);  // chunks per wavefront that still fill 256 CUs x 16 wavefronts
+            cpw = cpw > fill ? (fill < 1 ? 1 : fill) : cpw;
+            if (const char* e = getenv("KWS_X_MFCC_CPW")) cpw = atoi(e) > 0 ? atoi(e) : cpw;  // experiment: chunks per wavefront
+            const int waves_per_clip = (n_chunks + cpw - 1) / cpw;
+            const long waves = (long)nb * waves_per_clip;
+            RefineList r = rl;
+            r.clip0 = b0;
+            hipLaunchKernelGGL(kws_mfcc_i16_kernel, dim3((unsigned)((waves + MFCC_WAVES - 1) / MFCC_WAVES)), dim3(MFCC_THREADS), lds, s, p, t,
+                               d_wav + (size_t)b0 * p.n_samples, d_out + (size_t)b0 * p.num_frames * p.numcep, r, nb, cpw);
+        }
+        return hipGetLastError();
+    }
+#endif
+    return launch_mfcc_t(tail6 ? kws_mfcc_i16_tile_kernel : kws_mfcc_i16_any_kernel, s, p, t, d_wav, B, d_out, rl);
 }
 hipError_t launch_mfcc_f32_flag(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,
                                 float* d_out, const RefineList& rl) {
