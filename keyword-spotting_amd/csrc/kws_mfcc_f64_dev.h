@@ -220,6 +220,62 @@ __device__ __forceinline__ void spectrum_pair(d2* X, d2* P, const d2* tw_lds, in
 }
 
 
+// Samples of the frame pair (frame a = samples [sa, sa + frame_len) of clip xa, frame b likewise; pre-emphasised in float32
+// as NumPy does, zero beyond the frame and the clip) -> X[n] = (a[n], b[n]), n < nfft.  Returns through nza / nzb whether
+// the frames hold any non-zero sample.
+template <typename T, int NCT>
+__device__ __forceinline__ void f64_load_pair(const FrontendParams& p, const T* __restrict__ xa, long sa, const T* __restrict__ xb,
+                                              long sb, bool has_b, d2* X, int nfft, int n_used, int lane, bool& nza, bool& nzb) {
+    nza = false;
+    nzb = false;
+    if (sizeof(T) == 2 && p.vec_ok && (p.frame_step % 8) == 0) {
+        // 8 consecutive samples per lane and frame: one 16-byte load (every group is 16-byte aligned here), the sample
+        // before the group from the neighbouring lane's registers
+        for (int g = lane; 8 * g < nfft; g += 64) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) va[i] = vb[i] = 0.0;
+            auto load8 = [&](const T* __restrict__ x, long s0, double (&v)[8]) {
+                const long m0 = s0 + 8 * g;
+                if (8 * g < n_used && m0 < p.n_samples) {  // n_samples % 8 == 0: a group is inside the clip or outside it
+                    const uint4 raw = *reinterpret_cast<const uint4*>(x + m0);
+                    const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+                    float prev = m0 > 0 ? to_unit64(x[m0 - 1]) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float cur = to_unit64((int16_t)((wd[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+                        const float y = (m0 + i > 0) ? __fsub_rn(cur, __fmul_rn(p.preemph, prev)) : cur;
+                        v[i] = (8 * g + i < n_used) ? (double)y : 0.0;
+                        prev = cur;
+                    }
+                }
+            };
+            load8(xa, sa, va);
+            if (has_b) load8(xb, sb, vb);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                nza |= va[i] != 0.0;
+                nzb |= vb[i] != 0.0;
+                X[NCT == 512 ? sw512(8 * g + i) : 8 * g + i] = d2{va[i], vb[i]};
+            }
+        }
+    } else {
+        lane_loop<NCT>(lane, nfft, [&](int n) {
+            double a = 0.0, b = 0.0;
+            if (n < n_used) {
+                a = (double)preemph_sample(xa, sa + n, p.n_samples, p.preemph);
+                if (has_b) b = (double)preemph_sample(xb, sb + n, p.n_samples, p.preemph);
+            }
+            nza |= a != 0.0;
+            nzb |= b != 0.0;
+            X[NCT == 512 ? sw512(n) : n] = d2{a, b};
+        });
+    }
+    nza = __any(nza);
+    nzb = __any(nzb);
+    wave_order();
+}
+
 // Tables of the float64 tail: LDS copies (batched kernels) or the global tables themselves (the rare streaming redo).
 struct F64Tabs {
     const d2* tw;          // W_nfft^m: m < nfft/2 for a power-of-two length, m < nfft for the direct DFT
