@@ -3,11 +3,11 @@
 # (headline), mfcc-only (configs[1]), cnn-trad-fpool3 (configs[2] literal), ds-cnn at 1024 clips (configs[3] shard),
 # streaming push (configs[4]) -- rocprofv3 kernel statistics plus the two HBM-traffic counter passes (each counter in
 # its own pass with --kernel-trace only, never combined with sys/hip/hsa tracing).
-#   tools/collect_profiles.sh <round tag, e.g. r02> [workloads...]
+#   tools/collect_profiles.sh <round tag, e.g. r03> [workloads...]
 # Writes gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/.  Fails if a kernel-stats file does not
 # hold exactly spinup + warmup + steps calls of the workload's kernels.
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 WORKLOADS=${*:-"ds-cnn mfcc-only cnn-trad-fpool3 ds-cnn-1024 stream"}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -17,14 +17,14 @@ cd /tmp && export TMPDIR=/tmp
 SPIN=60; WARM=20
 for W in $WORKLOADS; do
   case $W in
-    ds-cnn)          STEPS=200; CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0 --configs none --no-parity"; KERNELS="kws_mfcc_i16_kernel kws_dscnn_fwd_kernel";;
-    mfcc-only)       STEPS=200; CMD="python $REPO/bench.py --model mfcc-only --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0"; KERNELS="kws_mfcc_i16_kernel";;
+    ds-cnn)          STEPS=200; CMD="python $REPO/bench.py --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0 --configs none --no-parity"; KERNELS="kws_mfcc_i16_kernel kws_mfcc_refine_kernel kws_dscnn_fwd_kernel";;
+    mfcc-only)       STEPS=200; CMD="python $REPO/bench.py --model mfcc-only --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0"; KERNELS="kws_mfcc_i16_kernel kws_mfcc_refine_kernel";;
     cnn-trad-fpool3) STEPS=100; CMD="python $REPO/bench.py --model cnn-trad-fpool3 --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0"; KERNELS="kws_mfcc_i16_kernel kws_cnntrad_conv_kernel kws_cnntrad_dense_kernel";;
     ds-cnn-1024)     STEPS=400; CMD="python $REPO/bench.py --batch 1024 --steps $STEPS --warmup $WARM --spinup $SPIN --cpu-sample 0 --configs none --no-parity"; KERNELS="kws_mfcc_i16_kernel kws_dscnn_fwd_kernel";;
     stream)          STEPS=300; CMD="python $REPO/tools/bench_stream.py 64 $STEPS eager"; KERNELS="kws_dscnn_fwd_kernel";;
     *) echo "unknown workload $W"; exit 1;;
   esac
-  EXPECT=$((SPIN + WARM + STEPS)); [ "$W" = stream ] && EXPECT=$STEPS
+  EXPECT=$((SPIN + WARM + STEPS)); [ "$W" = stream ] && EXPECT=$((STEPS + 60))   # bench_stream.py times the kernel over 60 more pushes
   echo "== $W: $CMD (expect $EXPECT calls per kernel)"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W/kt" -o kt -- $CMD > "$OUT/$W.kt.log" 2>&1 || { tail -5 "$OUT/$W.kt.log"; exit 1; }
   find "$OUT/$W/kt" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_${W}_kernel_stats.csv" \;
@@ -42,7 +42,7 @@ PY
   done
   # counter passes: short runs (5 timed steps), one counter per pass
   case $W in
-    stream) PCMD="python $REPO/tools/bench_stream.py 64 60 eager";;
+    stream) PCMD="python $REPO/tools/bench_stream.py 64 40 eager";;
     *)      PCMD="${CMD/--steps $STEPS --warmup $WARM --spinup $SPIN/--steps 5 --warmup 1 --spinup 4}";;
   esac
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/$W/fetch" -o fetch -- $PCMD > "$OUT/$W.fetch.log" 2>&1 || { tail -5 "$OUT/$W.fetch.log"; exit 1; }
@@ -53,7 +53,7 @@ done
 python3 - "$OUT" "$TAG" $WORKLOADS <<'PY'
 import csv, json, sys, collections, os
 out, tag, workloads = sys.argv[1], sys.argv[2], sys.argv[3:]
-KEYS = ("kws_mfcc_i16_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel", "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel")
+KEYS = ("kws_mfcc_i16_kernel", "kws_mfcc_refine_kernel", "kws_dscnn_fwd_kernel", "kws_cnntrad_conv_kernel", "kws_cnntrad_dense_kernel", "kws_stream_frame_kernel")
 def per_kernel(path, counter):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))  # kernel -> dispatch -> sum over instances
     for r in csv.DictReader(open(path)):

@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 counter passes for bench.py (run on the GPU box; counters in their own passes, never with
-# sys/hip/hsa tracing).  Usage: tools/pmc_passes.sh <outdir-under-gpurun_out> [tag]
+# sys/hip/hsa tracing).  Usage: tools/pmc_passes.sh <outdir-under-gpurun_out>
+# KWS_HIP_LIB=<variant .so> in the environment profiles another build of the same ABI (e.g. the round-2 tile kernel:
+# tools/build_variant.sh tile -DKWS_X_MFCC_TILE_KERNEL), for before / after counters from one box.
 set -o pipefail
 OUT=/root/repo/gpurun_out/${1:-pmc}
 mkdir -p "$OUT"
@@ -16,7 +18,8 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))  # kernel -> counter -> dispatch -> sum over instances
 for f in glob.glob(os.path.join(out, "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = "dscnn" if "dscnn" in r["Kernel_Name"] else "mfcc" if "mfcc" in r["Kernel_Name"] else None
+        n = r["Kernel_Name"]
+        k = "dscnn" if "dscnn" in n else "refine" if "mfcc_refine" in n else "mfcc" if "mfcc" in n else None
         if k: agg[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
 with open(os.path.join(out, "summary.txt"), "w") as fh:
     fh.write("# per launch of 4096 clips (sum over the counter's instances, mean over launches); bench.py --steps 5 --warmup 1 --spinup 4 --configs none\n")
