@@ -385,7 +385,12 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                                             float* __restrict__ act4 = nullptr, PosRange rg = PosRange{0, 0}) {
     using G = Blk<N>;
     const int p_lo = RANGED ? rg.lo : 0, p_hi = RANGED ? rg.hi : G::POUT;
+#ifdef KWS_X_DSCNN_SKIP_LEFTOVER  // timing experiment (wrong results): block 2 without its ninth tile, the upper bound of what
+                                  // spreading that tile over idle wavefronts could win
+    const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : (N == 2 ? 8 : G::TILES);
+#else
     const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : G::TILES;
+#endif
     constexpr bool MFMA = MODE != 0;
     constexpr bool SPLIT = MODE >= 4;  // input channel of step s: 16(s>>3) + 8*half + (s&7) instead of 2s + half
     // timing ablation of the split path (wrong results by construction): 6 = split + matrix core without the stencil
