@@ -43,7 +43,7 @@ def run(S, hops, use_graph, cluster=0):
     if not use_graph:  # the kernel's own duration (HIP events on the stream), 60 more pushes
         ctx.prof_enable(1); ctx.prof_reset()
         for t in range(60):
-            hop.copy_(pcm[t]); torch.cuda.synchronize()
+            hop.copy_(pcm[t % hops]); torch.cuda.synchronize()
             ctx.stream_push_i16(hop, logits, labels)
         ms, n = ctx.prof_read(_native.KWS_K_DSCNN)
         kern = ms / max(n, 1) * 1e3
