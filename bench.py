@@ -713,15 +713,14 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
         lat = np.array(lat[warm:hops - extra])
         res[mode] = {"p50_us": float(np.percentile(lat, 50)), "p90_us": float(np.percentile(lat, 90)),
                      "p99_us": float(np.percentile(lat, 99)), "mean_us": float(lat.mean()), "hops_timed": int(len(lat))}
-        if True:
-            k_ms, k_n = ctx.prof_read(_native.KWS_K_DSCNN)
-            f_ms, f_n = ctx.prof_read(_native.KWS_K_STREAM_FRAME)
-            ctx.prof_enable(False)
-            # one launch per push: the one-frame front end runs in the prologue of the DS-CNN kernel (f_n == 0)
-            res[mode]["kernel_us"] = {_native.kernel_name(_native.KWS_K_DSCNN): k_ms / max(k_n, 1) * 1e3}
-            if f_n:
-                res[mode]["kernel_us"][_native.kernel_name(_native.KWS_K_STREAM_FRAME)] = f_ms / f_n * 1e3
-            res[mode]["launches_per_push"] = 2 if f_n else 1
+        k_ms, k_n = ctx.prof_read(_native.KWS_K_DSCNN)
+        f_ms, f_n = ctx.prof_read(_native.KWS_K_STREAM_FRAME)
+        ctx.prof_enable(False)
+        # one launch per push: the one-frame front end runs in the prologue of the DS-CNN kernel (f_n == 0)
+        res[mode]["kernel_us"] = {_native.kernel_name(_native.KWS_K_DSCNN): k_ms / max(k_n, 1) * 1e3}
+        if f_n:
+            res[mode]["kernel_us"][_native.kernel_name(_native.KWS_K_STREAM_FRAME)] = f_ms / f_n * 1e3
+        res[mode]["launches_per_push"] = 2 if f_n else 1
         if primary:
             res[mode]["workgroups_per_stream"] = 4 if S <= 64 else (2 if S <= 128 else 1)
             dscnn_ms, dscnn_n = k_ms / max(k_n, 1), k_n

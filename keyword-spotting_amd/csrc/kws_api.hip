@@ -743,7 +743,6 @@ static int forward_map_impl(kws_ctx* c, const float* d_feat, int B, int T, int F
     float* bufs[2] = {c->d_conv_ws, c->d_conv_ws + (size_t)chunk * per_clip_max};
     float* dw_ws = c->d_conv_ws + 2 * (size_t)chunk * per_clip_max;
     const float* raw = c->mw.raw + (size_t)6400 * Cin + 64;        // first block's parameters in state_dict order
-    size_t layer_off = 0;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = B - b0 < chunk ? B - b0 : chunk;
         HIP_TRY(c, launch_conv1_any(c->stream, d_feat + (size_t)b0 * Cin * T * F, nb, Cin, T, F, c->mw.c1_general, c->mw.c1_b, bufs[0]));
@@ -767,9 +766,7 @@ static int forward_map_impl(kws_ctx* c, const float* d_feat, int B, int T, int F
         }
         HIP_TRY(c, launch_pool_fc(c->stream, bufs[cur], nb, H * W, c->mw.fc_w, c->mw.fc_b, C, d_logits + (size_t)b0 * C,
                                   d_label ? d_label + b0 : nullptr));
-        layer_off = lo;
     }
-    (void)layer_off;
     return KWS_OK;
 }
 

@@ -505,7 +505,11 @@ hipError_t launch_mfcc_flag(hipStream_t s, const FrontendParams& p, const Fronte
             int cpw = (n_chunks + wpc - 1) / wpc;
             const int fill = (int)(((long)nb * n_chunks + 4095) / 4096);  // chunks per wavefront that still fill 256 CUs x 16 wavefronts
             cpw = cpw > fill ? (fill < 1 ? 1 : fill) : cpw;
-            if (const char* e = getenv("KWS_X_MFCC_CPW")) cpw = atoi(e) > 0 ? atoi(e) : cpw;  // experiment: chunks per wavefront
+            static const int cpw_env = [] {  // experiment hook, read once (profiles/r03_mfcc_ab.txt: the chunks-per-wavefront scan)
+                const char* e = getenv("KWS_X_MFCC_CPW");
+                return e ? atoi(e) : 0;
+            }();
+            if (cpw_env > 0) cpw = cpw_env > 16 ? 16 : cpw_env;
             const int waves_per_clip = (n_chunks + cpw - 1) / cpw;
             const long waves = (long)nb * waves_per_clip;
             RefineList r = rl;

@@ -307,7 +307,7 @@ __device__ __forceinline__ void f64_tail(const FrontendParams& p, const F64Tabs&
     if (ea == 0.0) ea = PSF_EPS64;
     if (eb == 0.0) eb = PSF_EPS64;
 #ifdef KWS_X_F64_NOTAIL
-    if (lane < p.numcep) out_a[lane] = (float)(ea + eb);  // timing ablation
+    if (out_a && lane < p.numcep) out_a[lane] = (float)(ea + eb);  // timing ablation (out_a is null for a row the refinement does not rewrite)
     return;
 #endif
     // Mel filter j = rising edge over [e_j, e_j+1) + falling edge over [e_j+1, e_j+2); the per-bin weights come from

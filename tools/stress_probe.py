@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Diagnostics (GPU box): logit error of the fused path on the 48 diverse + 16 speech-like clips under the three stress weight
+tags (tests/golden/stress_golden.npz: he, he5, raw), with the selective refinement on and off."""
 import os, sys, numpy as np, torch
 ROOT="/root/repo"; sys.path.insert(0, ROOT); sys.path.insert(0, ROOT+"/keyword-spotting_amd")
 from kws import _native
