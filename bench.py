@@ -474,6 +474,18 @@ def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):
                 res[tag] = (time.perf_counter() - t0) / max(20, steps // 2) * 1e3
             out["refinement"]["golden_mix"] = {"ms_per_step_refinement_off": res["off"], "ms_per_step_refinement_on": res["on"],
                                                "frames_recomputed_per_step": ctx.frontend_stats()[2], "frames_per_step": B * 99}
+            # and the step's own clips with the refinement off: what the flag + the second launch cost on noise
+            ctx.set_frontend_refine(0.0)
+            for _ in range(10):
+                step()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(max(20, steps // 2)):
+                step()
+            ctx.sync()
+            off_ms = (time.perf_counter() - t0) / max(20, steps // 2) * 1e3
+            out["refinement"]["this_workload_refinement_off"] = {"ms_per_step": off_ms, "clips_per_s": B / (off_ms * 1e-3),
+                                                                 "note": "the float32 kernel alone: uniform noise stays within 9e-5 of the float64 oracle anyway, a clean tone over a quiet floor misses 1e-4 by up to 6x"}
         except Exception as e:
             out["refinement"]["golden_mix"] = {"error": f"{type(e).__name__}: {e}"}
         ctx.set_frontend_refine(_native.FE_REFINE_SPAN_DEFAULT)

@@ -653,7 +653,7 @@ int kws_mfcc_i16(kws_ctx* c, const int16_t* d_wav, int B, float* d_out) {
             HIP_TRY(c, launch_mfcc_flag(c->stream, p, c->ft, d_wav, B, d_out, rl));
         }
         ProfScope ps(c, KWS_K_MFCC_REFINE);
-        HIP_TRY(c, launch_mfcc_refine(c->stream, p, c->ft, d_wav, d_out, rl));
+        HIP_TRY(c, launch_mfcc_refine(c->stream, p, c->ft, d_wav, d_out, rl, B));
         return KWS_OK;
     }
     ProfScope ps(c, KWS_K_MFCC);
@@ -682,7 +682,7 @@ int kws_mfcc_f32(kws_ctx* c, const float* d_wav, int B, float* d_out) {
             HIP_TRY(c, launch_mfcc_f32_flag(c->stream, c->fp, c->ft, d_wav, B, d_out, rl));
         }
         ProfScope ps(c, KWS_K_MFCC_REFINE);
-        HIP_TRY(c, launch_mfcc_refine_f32in(c->stream, c->fp, c->ft, d_wav, d_out, rl));
+        HIP_TRY(c, launch_mfcc_refine_f32in(c->stream, c->fp, c->ft, d_wav, d_out, rl, B));
         return KWS_OK;
     }
     ProfScope ps(c, KWS_K_MFCC);

@@ -104,9 +104,9 @@ hipError_t launch_mfcc_f32_flag(hipStream_t s, const FrontendParams& p, const Fr
                                 float* d_out, const RefineList& rl);
 // Float64 recomputation of the listed frames, in place in d_out (same d_wav / d_out as the float32 launch before it).
 hipError_t launch_mfcc_refine(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, float* d_out,
-                              const RefineList& rl);
+                              const RefineList& rl, int B);
 hipError_t launch_mfcc_refine_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, float* d_out,
-                                    const RefineList& rl);
+                                    const RefineList& rl, int B);
 // The float64 front end: any nfft (power of two up to 4096: FFT; otherwise up to 2048: direct DFT), any frame length.
 hipError_t launch_mfcc_f64(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B, float* d_out);
 hipError_t launch_mfcc_f64_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, int B,

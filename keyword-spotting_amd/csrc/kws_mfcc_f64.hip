@@ -268,24 +268,28 @@ hipError_t launch_mfcc_f64_t(hipStream_t s, const FrontendParams& p, const Front
 constexpr int REFINE_GRID = KWS_X_REFINE_GRID;
 template <typename T>
 hipError_t launch_mfcc_refine_t(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const T* d_wav, float* d_out,
-                                const RefineList& rl) {
+                                const RefineList& rl, int B) {
     const size_t lds = f64_layout(512, true, true, p.nfilt, p.numcep, REFINE_WAVES).total;
     auto kernel = kws_mfcc_refine_kernel<T>;
     hipError_t e = raise_lds_limit(kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(REFINE_GRID), dim3(REFINE_WAVES * 64), lds, s, p, t, d_wav, d_out, rl);
+    // workgroups cost time even when they leave at once (~3.5 us per 256 of them): a small batch, whose list is short in
+    // proportion, gets a smaller grid -- one workgroup per 16 clips, between 32 and REFINE_GRID
+    int grid = (B + 15) / 16;
+    grid = grid < 32 ? 32 : (grid > REFINE_GRID ? REFINE_GRID : grid);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(REFINE_WAVES * 64), lds, s, p, t, d_wav, d_out, rl);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_mfcc_refine(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, float* d_out,
-                              const RefineList& rl) {
-    return launch_mfcc_refine_t(s, p, t, d_wav, d_out, rl);
+                              const RefineList& rl, int B) {
+    return launch_mfcc_refine_t(s, p, t, d_wav, d_out, rl, B);
 }
 hipError_t launch_mfcc_refine_f32in(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const float* d_wav, float* d_out,
-                                    const RefineList& rl) {
-    return launch_mfcc_refine_t(s, p, t, d_wav, d_out, rl);
+                                    const RefineList& rl, int B) {
+    return launch_mfcc_refine_t(s, p, t, d_wav, d_out, rl, B);
 }
 
 hipError_t launch_mfcc_f64(hipStream_t s, const FrontendParams& p, const FrontendTables& t, const int16_t* d_wav, int B, float* d_out) {
