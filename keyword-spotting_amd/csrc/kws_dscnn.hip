@@ -93,6 +93,28 @@ struct Blk {
     static constexpr int BUF = (N - 1) & 1;                       // which depthwise / bias buffer it reads
 };
 
+// Leftover tiles (round 3).  Block 1 has 5 tiles and block 2 has 9 for 8 wavefronts: the fifth / ninth tile costs a whole
+// extra unit on one wavefront while others idle (block 2: 12.5 k cycles for 9 tiles, block 3: 13 k for 12).  With
+// KWS_DSCNN_KSPLIT_LEFTOVER that tile is cut along K instead: four wavefronts take one k-block (16 input channels, 8 steps)
+// each, write their 64 x positions partial sums to a dead region of LDS, and after the block's barrier all threads add the
+// four partials in a fixed order, add the bias, apply ReLU and store (leftover_combine; one more barrier).  Block 1: tiles
+// 0-3 on wavefronts 0-3, the leftover on 4-7 (one per SIMD); block 2: tiles 0-7 on all eight, the leftover as a second,
+// quarter-size unit of the older wavefronts 0-3.
+#ifndef KWS_DSCNN_KSPLIT_LEFTOVER
+#define KWS_DSCNN_KSPLIT_LEFTOVER 1
+#endif
+template <int N>
+struct Leftover {
+    static constexpr bool HAS = KWS_DSCNN_KSPLIT_LEFTOVER && (N == 1 || N == 2);
+    static constexpr int TILE = N == 1 ? 4 : 8;                     // the tile that is K-split
+    static constexpr int P0T = TILE * TW;                           // its first position
+    static constexpr int NP = HAS ? Blk<N>::POUT - P0T : 1;         // its positions: 21 (block 1), 5 (block 2)
+    static constexpr int WAVE0 = N == 1 ? 4 : 0;                    // wavefronts WAVE0 .. WAVE0 + 3 take k-blocks 0 .. 3
+    static constexpr int OFF_PART = N == 1 ? OFF_Z2 : OFF_Z0;       // [4][64][NP] partial sums, in a plane that is dead during block N
+};
+static_assert(Blk<1>::TILES == 5 && Blk<2>::TILES == 9, "the leftover tiles are the fifth of block 1 and the ninth of block 2");
+static_assert(4 * CH * Leftover<1>::NP <= 38784 - OFF_Z2 && OFF_Z0 + 4 * CH * Leftover<2>::NP <= OFF_FEAT, "partial sums fit their dead planes");
+
 // Depthwise 3x3 (+bias) at this lane's column from its three own-column inputs: nine multiply-adds and two
 // fused DPP multiply-adds that pull the neighbouring lanes' column sums across the wavefront (0 shifted in at the
 // ends).  Written as one asm block so that (a) the shift and the multiply-add are one instruction each
@@ -371,6 +393,82 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// A quarter of the leftover tile of block N (see Leftover): k-block M (input channels 16M .. 16M+15) of tile Leftover<N>::TILE
+// for both output-channel tiles.  Eight stencil steps, one split, twelve MFMAs, the raw partial sums (no bias, no ReLU) of the
+// tile's valid columns to part[M][cout][position in tile].  af: the pre-split weights of k-block M (requested long before).
+template <int N>
+__device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int M, const AFrag& af) {
+    using G = Blk<N>;
+    using L = Leftover<N>;
+    const int half = lane >> 5, col = lane & 31;
+    const float* dwtab = lds + OFF_DWTAB + G::BUF * 768;
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;
+    const int pos = L::P0T - 1 + col;
+    const bool valid = col >= 1 && col <= TW && pos < G::POUT;
+    const int posc = pos < G::POUT ? pos : G::POUT - 1;  // (pos >= P0T - 1 >= 0)
+    const int h = posc / G::W, x = posc % G::W;
+    const float mask_l = x > 0 ? 1.f : 0.f, mask_r = x < G::W - 1 ? 1.f : 0.f;
+    int ta[3];  // own-column tap addresses (rows h-1, h, h+1) of channel pair 8 * half, as float indices into lds
+#pragma unroll
+    for (int dh = -1; dh <= 1; ++dh) {
+        const int o = G::RING ? 1 : 0;
+        const int hh = h + dh - o, xx = x - o;
+        const bool inside = (unsigned)hh < (unsigned)G::HI && (unsigned)xx < (unsigned)G::WI;
+        const bool in_map = (unsigned)(h + dh) < (unsigned)G::H;
+        const int a = inside ? hh * G::WI + xx : ((G::RING && in_map) ? G::PIN : G::PIN + 1);
+        ta[dh + 1] = G::OFF_IN + pidx(half * 8, a, G::SIN);
+    }
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {  // channels (cs, cs + 1) = 16M + j, + 1 (+ 8 * half through the addresses)
+        const int cs = 16 * M + j;
+        const int o = cs * G::SIN;    // pair-interleaved planes: channel pair cs / 2 starts at (cs / 2) * 2 * SIN
+        const float2 up = *reinterpret_cast<const float2*>(lds + ta[0] + o);
+        const float2 mid = *reinterpret_cast<const float2*>(lds + ta[1] + o);
+        const float2 dn = *reinterpret_cast<const float2*>(lds + ta[2] + o);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float4 q0 = dwt4[(cs + e) * 3 + 0], q1 = dwt4[(cs + e) * 3 + 1], q2 = dwt4[(cs + e) * 3 + 2];
+            y[j + e] = stencil3x3<false>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, e ? up.y : up.x, e ? mid.y : mid.x,
+                                         e ? dn.y : dn.x, mask_l, mask_r);
+        }
+    }
+    uintx4 bh, bm, bl;
+    split3(y, bh, bm, bl);
+    floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {  // the six piece products, smallest first
+        const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+        const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
+        acc0 = mfma_bf16(af[0][pa], b, acc0);
+        acc1 = mfma_bf16(af[1][pa], b, acc1);
+    }
+    float* part = lds + L::OFF_PART + M * (CH * L::NP);
+    if (valid) {  // (plain stores of the accumulators: the compiler waits out the matrix-core write itself)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            part[row_of(r, half) * L::NP + (col - 1)] = acc0[r];
+            part[(32 + row_of(r, half)) * L::NP + (col - 1)] = acc1[r];
+        }
+    }
+}
+
+// After the block's barrier: the leftover tile's output = relu(bias + the four k-block partials, added in a fixed order).
+template <int N>
+__device__ __forceinline__ void leftover_combine(float* lds, int tid) {
+    using G = Blk<N>;
+    using L = Leftover<N>;
+    const float* part = lds + L::OFF_PART;
+    const float* pwb = lds + OFF_PWB + G::BUF * 64;
+    float* zout = lds + G::OFF_OUT;
+    for (int i = tid; i < CH * L::NP; i += NT) {
+        const int co = i / L::NP, j = i - co * L::NP;
+        const float s = (part[i] + part[CH * L::NP + i]) + (part[2 * CH * L::NP + i] + part[3 * CH * L::NP + i]);
+        zout[pidx(co, L::P0T + j, G::SOUT)] = relu(s + pwb[co]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One depthwise-separable block.  pwo: pointwise operands of THIS block on entry (f32: all of them; split:
 // k-block 0 in ring[0]); on exit (N < 4) the loads of the next block's have been issued into it, so they fly
 // across the barrier.
@@ -384,12 +482,14 @@ template <int N, int MODE, bool RANGED = false>
 __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo,
                                             float* __restrict__ act4 = nullptr, PosRange rg = PosRange{0, 0}) {
     using G = Blk<N>;
+    // the leftover tile of blocks 1 / 2 is K-split over four wavefronts (product path on whole maps only)
+    constexpr bool KSL = Leftover<N>::HAS && MODE == 4 && !RANGED;
     const int p_lo = RANGED ? rg.lo : 0, p_hi = RANGED ? rg.hi : G::POUT;
 #ifdef KWS_X_DSCNN_SKIP_LEFTOVER  // timing experiment (wrong results): block 2 without its ninth tile, the upper bound of what
                                   // spreading that tile over idle wavefronts could win
     const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : (N == 2 ? 8 : G::TILES);
 #else
-    const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : G::TILES;
+    const int n_tiles = RANGED ? (p_hi - p_lo + TW - 1) / TW : (KSL ? Leftover<N>::TILE : G::TILES);
 #endif
     constexpr bool MFMA = MODE != 0;
     constexpr bool SPLIT = MODE >= 4;  // input channel of step s: 16(s>>3) + 8*half + (s&7) instead of 2s + half
@@ -546,6 +646,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                             load_afrag(w, N, m + 1, lane, pwo.ring[(m + 1) & 1]);
                         else if (t + NW < n_tiles)
                             load_afrag(w, N, 0, lane, pwo.ring[0]);
+                        else if (KSL && N == 2 && wv < 4)
+                            load_afrag(w, N, wv, lane, pwo.ring[0]);  // this wavefront's quarter of the leftover tile comes next
                         else if (N < 4)
                             load_afrag(w, N < 4 ? N + 1 : N, 0, lane, pwo.ring[0]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -679,10 +781,18 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
         }
     }
 
+    if constexpr (KSL) {
+        using L = Leftover<N>;
+        if (wv >= L::WAVE0 && wv < L::WAVE0 + 4) {
+            leftover_partial_unit<N>(lds, lane, wv - L::WAVE0, pwo.ring[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_afrag(w, N + 1, 0, lane, pwo.ring[0]);  // the next block's first operands fly across the barrier
+        }
+    }
     if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
-            if (wv >= n_tiles) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
+            if (wv >= n_tiles && !(KSL && N == 1)) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
         } else {
             // reduce the pool partials over the positions held by each half-wave (DPP, no LDS round trips).  Step-major:
             // all 32 sums take a shift step before any takes the next, so a value is read by DPP well after it was written and
@@ -853,7 +963,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             lds[OFF_Z0 + pidx(tid, P0 + 1, P0 + 2)] = 0.f;
         }
         store_block_tables(lds, 1, tid, t1);
-        load_block_head(w, 1, lane, wa);
+        if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER)
+            load_afrag(w, 1, wv >= 4 ? wv - 4 : 0, lane, wa.ring[0]);  // wavefronts 4-7: their k-block of block 1's leftover tile
+        else
+            load_block_head(w, 1, lane, wa);
         stamp();  // 1
     } else {
     // ---- phase 0: MFCC map -> zero-padded [103][14] in LDS, weight loads in flight --------------------
@@ -940,7 +1053,11 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
 
     if constexpr (SPLIT) {
         conv1_phase_split<CLUSTER>(w, lds, tid, c1f, rg0);
-        load_block_head(w, 1, lane, wa);  // the conv1 operands are dead: block 1's first fly across the barrier
+        // the conv1 operands are dead: block 1's first fly across the barrier (wavefronts 4-7: their k-block of the leftover tile)
+        if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER)
+            load_afrag(w, 1, wv >= 4 ? wv - 4 : 0, lane, wa.ring[0]);
+        else
+            load_block_head(w, 1, lane, wa);
     } else {
         conv1_phase<MFMA>(w, lds, tid, a1);
     }
@@ -957,6 +1074,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     block_phase<1, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg1);
     stamp();  // 4: block 1 units of wave 0 done
     __syncthreads();
+    if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER) {
+        leftover_combine<1>(lds, tid);
+        __syncthreads();
+    }
     stamp();  // 5: block 1 barrier
     if (a) {
         for (int i = tid; i < CH * Blk<1>::POUT; i += NT)
@@ -966,6 +1087,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     block_phase<2, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg2);
     stamp();  // 6
     __syncthreads();
+    if constexpr (Leftover<2>::HAS && MODE == 4 && !CLUSTER) {
+        leftover_combine<2>(lds, tid);
+        __syncthreads();
+    }
     stamp();  // 7
     if (a) {
         for (int i = tid; i < CH * Blk<2>::POUT; i += NT)
