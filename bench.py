@@ -700,11 +700,16 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
     pcm = torch.from_numpy(pcm_host).to(dev)
     res = {}
     final_logits = None
-    for mode, use_graph, cluster in (("eager", False, 0), ("one_workgroup_per_stream", False, 1)):
+    # "eager": push -> kws_sync (results complete in DEVICE memory); "host_results": push -> kws_stream_wait_host (the kernel
+    # wrote logits + labels to pinned host memory and raised a flag there: results readable by the HOST, no synchronise, no copy)
+    for mode, use_graph, cluster in (("eager", False, 0), ("host_results", False, 0), ("one_workgroup_per_stream", False, 1)):
         ctx = _native.Context(dev.index)
         ctx.load_dscnn(blob, NUM_CLASSES)
         ctx.stream_open(S)
         ctx.stream_cluster(cluster)
+        host = mode == "host_results"
+        if host:
+            ctx.stream_host_results(True)
         hop = torch.empty((S, 160), dtype=torch.int16, device=dev)
         logits = torch.empty((S, NUM_CLASSES), dtype=torch.float32, device=dev)
         labels = torch.empty((S,), dtype=torch.int32, device=dev)
@@ -720,7 +725,10 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
                 ctx.prof_reset()
             t0 = time.perf_counter()
             ctx.stream_push_i16(hop, logits, labels, use_graph=use_graph)
-            ctx.sync()
+            if host:
+                h_logits, h_labels = ctx.stream_wait_host(S)
+            else:
+                ctx.sync()
             lat.append((time.perf_counter() - t0) * 1e6)
         lat = np.array(lat[warm:hops - extra])
         res[mode] = {"p50_us": float(np.percentile(lat, 50)), "p90_us": float(np.percentile(lat, 90)),
@@ -737,6 +745,11 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
             res[mode]["workgroups_per_stream"] = 4 if S <= 64 else (2 if S <= 128 else 1)
             dscnn_ms, dscnn_n = k_ms / max(k_n, 1), k_n
             final_logits = logits.cpu().numpy()
+        elif host:
+            ctx.sync()
+            res[mode]["workgroups_per_stream"] = res["eager"]["workgroups_per_stream"]
+            res[mode]["host_arrays_equal_device_arrays"] = bool(np.array_equal(h_logits, logits.cpu().numpy()) and np.array_equal(h_labels, labels.cpu().numpy())
+                                                                and np.array_equal(h_logits, final_logits))
         else:
             res[mode]["workgroups_per_stream"] = 1
             res[mode]["max_abs_logit_diff_vs_clustered"] = float(np.abs(final_logits - logits.cpu().numpy()).max())
@@ -744,9 +757,10 @@ def leg_stream(args, _native, torch, dev, blob, S, hops, cpu_check):
         ctx.close()
     best = min(res, key=lambda m: res[m]["p50_us"])
     out = {"workload": f"configs[4]: {S} concurrent streams, 10 ms hop (160 samples @ 16 kHz), per hop one MFCC frame per stream + DS-CNN over "
-                       "every stream's last 99 frames; latency = push -> labels complete",
+                       "every stream's last 99 frames; latency = push -> labels complete (host_results: readable in host memory; eager: "
+                       "complete in device memory)",
            "value": res[best]["p50_us"], "unit": "us p50 per hop", "higher_is_better": False, "p99_us": res[best]["p99_us"], "mode": best,
-           "eager": res["eager"], "one_workgroup_per_stream": res["one_workgroup_per_stream"],
+           "eager": res["eager"], "host_results": res["host_results"], "one_workgroup_per_stream": res["one_workgroup_per_stream"],
            "hipgraph": "not used for the one-launch push: replaying a one-node graph is 8 us slower than the plain launch on this stack "
                        "(tools/graph_overhead.hip, profiles/r03_graph_overhead.txt)",
            "real_time_factor_p50": 10000.0 / res[best]["p50_us"], "dtype": "f32",

@@ -250,6 +250,15 @@ int kws_stream_push_i16(kws_ctx* ctx, const int16_t* d_hop, float* d_logits, int
  * 4 up to 64 streams, 2 up to 128, else 1.  Logits of different shapes agree to the float32 rounding of the pooled sums
  * (their order of addition differs); a given shape is deterministic. */
 int kws_stream_cluster(kws_ctx* ctx, int workgroups_per_stream);
+/* Zero-copy result delivery for the one-launch push (the latency path of BASELINE config 5).  enable != 0: the context
+ * allocates pinned, device-mapped host arrays; from then on every push that asks for logits ALSO writes its logits
+ * [n_streams, C] and labels [n_streams] there with system-scope stores, and the workgroup that finishes last raises a flag in
+ * host memory.  kws_stream_wait_host spins on that flag (falling back to the stream after ~2 ms) and returns the host
+ * arrays (owned by the context, overwritten by the next push): the caller has the results in hand without a
+ * hipStreamSynchronize round trip and without a device-to-host copy.  d_logits / d_label of kws_stream_push_i16 are still
+ * written.  Call after kws_stream_open and kws_load_dscnn; kws_stream_open / kws_stream_close / enable == 0 release it. */
+int kws_stream_host_results(kws_ctx* ctx, int enable);
+int kws_stream_wait_host(kws_ctx* ctx, const float** h_logits, const int32_t** h_label);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
  * by the context) and the number of pushes so far; the newest frame is row (hops - K) mod num_frames, K = ceil(frame_len / frame_step)
  * hops per frame (3 for the reference's 400 / 160). */

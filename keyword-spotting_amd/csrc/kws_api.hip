@@ -1,6 +1,7 @@
 // C ABI of libkws_hip.so (declared in include/kws_hip.h): context, host-side table construction,
 // weight repacking, workspace and per-kernel event timing.  No torch types, no exceptions across the
 // boundary, no CPU fallback.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -855,9 +856,20 @@ static void drop_stream_graph(kws_ctx* c) {
     c->graph_key[0] = c->graph_key[1] = c->graph_key[2] = nullptr;
 }
 
+static void host_results_free(kws_ctx* c) {
+    if (c->h_stream_logits) (void)hipHostFree(c->h_stream_logits);
+    if (c->h_stream_label) (void)hipHostFree(c->h_stream_label);
+    if (c->h_stream_flag) (void)hipHostFree(c->h_stream_flag);
+    c->h_stream_logits = nullptr;
+    c->h_stream_label = nullptr;
+    c->h_stream_flag = nullptr;
+    c->host_results_classes = 0;
+}
+
 static void stream_free(kws_ctx* c) {
     smooth_free(c);
     vad_free(c);
+    host_results_free(c);
     if (c->stream_graph) (void)hipGraphExecDestroy(c->stream_graph);
     if (c->d_pcm_ring) (void)hipFree(c->d_pcm_ring);
     if (c->d_feat_ring) (void)hipFree(c->d_feat_ring);
@@ -895,6 +907,9 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
         return fail(c, KWS_ENOMEM, "kws_stream_open: device allocation failed");
     }
     c->n_streams = n_streams;
+    c->pushes_enqueued = 0;
+    c->host_push = 0;
+    c->last_push_host = false;
     if (c->refine_span > 0.f) {  // the pushes count the frames they redo in float64 in the refinement counters
         int rc = ensure_refine(c, 1);
         if (rc) return rc;
@@ -903,6 +918,61 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     HIP_TRY(c, hipMemsetAsync(c->d_feat_ring, 0, feat_b, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_hops, 0, 2 * sizeof(int), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_cl_count, 0, sizeof(int) * (size_t)n_streams, c->stream));
+    return KWS_OK;
+}
+
+int kws_stream_host_results(kws_ctx* c, int enable) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_host_results: call kws_stream_open first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    host_results_free(c);
+    if (!enable) return KWS_OK;
+    if (!c->model_ready) return fail(c, KWS_ESTATE, "kws_stream_host_results: no model loaded (kws_load_dscnn)");
+    const int C = c->mw.num_classes;
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;  // fine-grained: device stores are visible to the host as they land
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_logits), sizeof(float) * (size_t)c->n_streams * C, flags) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_label), sizeof(int32_t) * (size_t)c->n_streams, flags) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_flag), 64, flags) != hipSuccess) {
+        host_results_free(c);
+        return fail(c, KWS_ENOMEM, "kws_stream_host_results: pinned host allocation failed");
+    }
+    memset(c->h_stream_logits, 0, sizeof(float) * (size_t)c->n_streams * C);
+    memset(c->h_stream_label, 0, sizeof(int32_t) * (size_t)c->n_streams);
+    // the flag holds the device's push count: start it where the device stands
+    int hops = 0;
+    HIP_TRY(c, hipMemcpy(&hops, c->d_hops, sizeof(int), hipMemcpyDeviceToHost));
+    *c->h_stream_flag = hops;
+    c->pushes_enqueued = hops;
+    c->host_push = hops;
+    c->host_results_classes = C;
+    return KWS_OK;
+}
+
+int kws_stream_wait_host(kws_ctx* c, const float** h_logits, const int32_t** h_label) {
+    if (!c) return KWS_EINVAL;
+    if (!c->h_stream_flag) return fail(c, KWS_ESTATE, "kws_stream_wait_host: call kws_stream_host_results(ctx, 1) first");
+    // spin on the flag the last workgroup of the newest push raises; bounded: after ~2 ms without it, fall back to the stream
+    if (c->host_push != c->pushes_enqueued)
+        return fail(c, KWS_ESTATE, "kws_stream_wait_host: the newest push did not deliver to host memory (it asked for no logits, or took a multi-launch route)");
+    volatile int* flag = c->h_stream_flag;
+    const int want = c->host_push;
+    bool seen = false;
+    for (long spin = 0; spin < 4000000; ++spin) {
+        if (*flag - want >= 0) {
+            seen = true;
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    if (!seen) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (*flag - want < 0) return fail(c, KWS_EHIP, "kws_stream_wait_host: the stream drained but the results flag never arrived");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (h_logits) *h_logits = c->h_stream_logits;
+    if (h_label) *h_label = c->h_stream_label;
     return KWS_OK;
 }
 
@@ -1174,9 +1244,13 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         c->prof = was;
         // time-tile clusters while there are CUs to spare: 4 workgroups per stream up to 64 streams, 2 up to 128 (256 CUs)
         const int cluster = c->stream_cluster ? c->stream_cluster : (c->n_streams <= 64 ? 4 : (c->n_streams <= 128 ? 2 : 1));
-        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine, 0, cluster, c->d_cl_part, c->d_cl_count};
+        const bool host = c->h_stream_flag && c->host_results_classes == c->mw.num_classes;
+        const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine, 0, cluster, c->d_cl_part, c->d_cl_count,
+                               host ? c->h_stream_logits : nullptr, host ? c->h_stream_label : nullptr, host ? c->h_stream_flag : nullptr};
+        c->last_push_host = host;
         return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label);
     }
+    c->last_push_host = false;
     {
         const bool was = c->prof;
         c->prof = was && timed;
@@ -1233,9 +1307,12 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
             c->graph_key[2] = d_label;
         }
         HIP_TRY(c, hipGraphLaunch(c->stream_graph, c->stream));
+        c->pushes_enqueued += 1;
         return KWS_OK;
     }
     HIP_TRY(c, stream_enqueue(c, d_hop, d_logits, d_label, true));
+    c->pushes_enqueued += 1;
+    if (c->last_push_host) c->host_push = c->pushes_enqueued;
     return KWS_OK;
 }
 

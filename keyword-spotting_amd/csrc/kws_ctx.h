@@ -59,6 +59,14 @@ struct kws_ctx {
     int stream_cluster = 0;           // workgroups per stream of the fused push (kws_stream_cluster; 0 = by stream count)
     float* d_cl_part = nullptr;       // [n_streams][4][64] pooled partial sums of a stream's time tiles
     int* d_cl_count = nullptr;        // [n_streams]
+    // zero-copy result delivery of the one-launch push (kws_stream_host_results): pinned, device-mapped host memory
+    float* h_stream_logits = nullptr;  // [n_streams][num_classes at enable time]
+    int32_t* h_stream_label = nullptr;
+    int* h_stream_flag = nullptr;
+    int host_results_classes = 0;
+    int pushes_enqueued = 0;           // pushes since kws_stream_open = the device's hop counter once the stream has drained
+    int host_push = 0;                 // the newest push that delivers to host memory (the flag reads this when it is done)
+    bool last_push_host = false;
     hipGraphExec_t stream_graph = nullptr;
     const void* graph_key[3] = {nullptr, nullptr, nullptr};
     // posterior smoothing history (kws_stream_smooth_f32): ring [n_streams][window][C], sum [n_streams][C], hop count

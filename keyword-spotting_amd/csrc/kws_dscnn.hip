@@ -1188,6 +1188,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
                 acc = fmaf(a4.w, p4.w, acc);
             }
             logits[(size_t)clip * C + lane] = acc;
+            if constexpr (STREAM) {  // zero-copy delivery: the host's pinned copy, written through (system scope), see below
+                if (sp.h_logits) __hip_atomic_store(sp.h_logits + (size_t)clip * C + lane, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             v = acc;
         }
         // argmax, first maximum wins: wave maximum by DPP (no LDS round trips; six dependent __shfl_xor rounds through
@@ -1203,13 +1206,23 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const unsigned long long holders = __ballot(lane < C && v == vmax);
         const int idx = holders ? __ffsll(holders) - 1 : 0;  // all-NaN logits: label 0
         if (label && lane == 0) label[clip] = idx;
+        if constexpr (STREAM) {
+            if (sp.h_label && lane == 0) __hip_atomic_store(sp.h_label + clip, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if constexpr (STREAM) {
         // hop counter: every workgroup read sp.hops[0] in its prologue; the one that finishes last advances it
         // (sp.hops[1] counts finished workgroups).  The kernel boundary publishes it to the next push.
+        // Zero-copy result delivery (kws_stream_host_results): logits and labels also went to pinned host memory as
+        // system-scope stores; a workgroup bumps the counter only after its own have been acknowledged (vmcnt 0: they are
+        // on their way over PCIe, in order), and the last one raises the host's flag behind them -- posted writes of one
+        // device keep their order, so the host that sees the flag sees every stream's results.  No fence (they write whole
+        // L2s back on this part).
+        if (sp.h_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0 && atomicAdd(&sp.hops[1], 1) == (int)gridDim.x - 1) {
             sp.hops[1] = 0;
             sp.hops[0] = hops_before + 1;
+            if (sp.h_flag) __hip_atomic_store(sp.h_flag, hops_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     stamp();  // 12: pool + fc + argmax done

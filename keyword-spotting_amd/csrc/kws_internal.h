@@ -168,6 +168,9 @@ struct StreamPush {
     int cluster;             // workgroups per stream of the fused push (time tiles; 1 = one workgroup owns the stream's network)
     float* cl_part;          // [n_streams][cluster][64] pooled partial sums of the tiles
     int* cl_count;           // [n_streams] tiles that have delivered theirs (the last one runs fc + argmax and clears it)
+    float* h_logits;         // zero-copy delivery (kws_stream_host_results): pinned host [n_streams][C], or NULL
+    int32_t* h_label;        // pinned host [n_streams], or NULL
+    int* h_flag;             // pinned host: the push count whose results are complete in h_logits / h_label
 };
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
                                float* d_logits, int32_t* d_label);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "kws_stream_open": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_close": (C.c_int, [_c_ctx]),
     "kws_stream_cluster": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_stream_host_results": (C.c_int, [_c_ctx, C.c_int]),
+    "kws_stream_wait_host": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "kws_stream_push_i16": (C.c_int, [_c_ctx, _i16p, _f32p, _i32p, C.c_int]),
     "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
@@ -329,6 +331,22 @@ class Context:
     def stream_cluster(self, workgroups_per_stream: int = 0):
         """Workgroups per stream of the one-launch push: 1, or 2 / 4 time tiles; 0 = by stream count (``kws_stream_cluster``)."""
         self._check(self._lib.kws_stream_cluster(self._h, int(workgroups_per_stream)), ModelError)
+
+    def stream_host_results(self, enable: bool = True):
+        """Zero-copy delivery of the one-launch push's logits / labels to pinned host memory (``kws_stream_host_results``)."""
+        self._check(self._lib.kws_stream_host_results(self._h, 1 if enable else 0), ModelError)
+        self._host_views = None
+
+    def stream_wait_host(self, n_streams: int):
+        """Spin until the newest push's results are in host memory; returns numpy VIEWS (logits float32[S,C], labels int32[S])
+        of the context's pinned arrays -- valid until the next push."""
+        pl, py = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.kws_stream_wait_host(self._h, C.byref(pl), C.byref(py)), ModelError)
+        if getattr(self, "_host_views", None) is None or self._host_views[0] != (pl.value, py.value, n_streams):
+            lg = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_float)), shape=(n_streams, self.num_classes))
+            lb = np.ctypeslib.as_array(C.cast(py, C.POINTER(C.c_int32)), shape=(n_streams,))
+            self._host_views = ((pl.value, py.value, n_streams), lg, lb)
+        return self._host_views[1], self._host_views[2]
 
     def stream_close(self):
         self._check(self._lib.kws_stream_close(self._h))

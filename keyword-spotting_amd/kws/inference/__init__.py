@@ -134,7 +134,7 @@ class StreamingSpotter:
 
     def __init__(self, n_streams: int, model: Optional[DepthwiseSeparableConv] = None, words: Sequence[str] = WANTED_WORDS,
                  config: Optional[AudioConfig] = None, device: int = 0, use_graph: bool = False, smooth_window: int = 0,
-                 vad_log_energy: Optional[float] = None, vad_windows: Tuple[int, int] = (40, 80)):
+                 vad_log_energy: Optional[float] = None, vad_windows: Tuple[int, int] = (40, 80), host_results: bool = True):
         from kws import _native
 
         self.config = config or AudioConfig()
@@ -167,6 +167,11 @@ class StreamingSpotter:
         self.vad_windows = (int(vad_windows[0]), int(vad_windows[1]))
         self._vad = torch.zeros((self.n_streams,), dtype=torch.int32, device=self.device) if vad_log_energy is not None else None
         self.vad_state: Optional[np.ndarray] = None
+        # zero-copy delivery (kws_stream_host_results): the push's own kernel writes logits and labels to pinned host memory
+        # and raises a flag there, so a plain push returns without a stream synchronise or a device-to-host copy
+        self._host = bool(host_results) and self.smooth_window == 0 and self._vad is None
+        if self._host:
+            self._ctx.stream_host_results(True)
         torch.cuda.synchronize(self.device)
 
     def load_model(self, model: DepthwiseSeparableConv) -> None:
@@ -186,6 +191,9 @@ class StreamingSpotter:
         self._hop_buf.copy_(x, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()  # the context runs on its own stream
         self._ctx.stream_push_i16(self._hop_buf, self._logits, self._labels, use_graph=self.use_graph)
+        if self._host:
+            lg, lb = self._ctx.stream_wait_host(self.n_streams)
+            return lb.copy(), lg.copy()
         if self._vad is not None:
             self._ctx.stream_vad_f32(self.vad_log_energy, self.vad_windows[0], self.vad_windows[1], self._vad)
         if self.smooth_window > 0:

@@ -1515,6 +1515,46 @@ def test_streaming_time_tile_clusters_agree(native, dev, e2e_golden, use_graph):
     assert all(np.array_equal(x[1], y[1]) for x, y in zip(runs[0][0][0], a[0]))             # automatic == 4 tiles at 64 streams
 
 
+def test_streaming_host_results_are_the_device_results(native, dev, e2e_golden):
+    """Zero-copy delivery (kws_stream_host_results / kws_stream_wait_host): the one-launch push writes logits and labels to
+    pinned host memory and raises a flag there.  What the host reads after the wait is bit for bit what the device arrays
+    hold, at every push, for 1, 64 (4 tiles per stream) and 257 streams; a spotter without it returns the same; the
+    wait refuses when the newest push delivered nothing (features only) and before the delivery is enabled."""
+    from kws.inference import StreamingSpotter
+    from kws.common.errors import ModelError
+
+    model = he_model(e2e_golden)
+    rng = np.random.default_rng(77)
+    for S, hops in ((1, 30), (64, 110), (257, 12)):
+        pcm = rng.integers(-12000, 12000, size=(S, hops * 160), dtype=np.int16)
+        a = StreamingSpotter(S, model)                      # host results (the default)
+        b = StreamingSpotter(S, model, host_results=False)  # stream synchronise + device-to-host copies
+        try:
+            assert a._host and not b._host
+            for t in range(hops):
+                la, ga = a.push(pcm[:, t * 160:(t + 1) * 160])
+                lb, gb = b.push(pcm[:, t * 160:(t + 1) * 160])
+                assert np.array_equal(ga, gb) and np.array_equal(la, lb), (S, t)
+                a._ctx.sync()
+                assert np.array_equal(ga, a._logits.cpu().numpy()) and np.array_equal(la, a._labels.cpu().numpy()), (S, t)
+            # a features-only push delivers nothing: the wait says so instead of returning the previous hop's results
+            a._ctx.stream_push_i16(a._hop_buf, None, None)
+            with pytest.raises(ModelError, match="did not deliver"):
+                a._ctx.stream_wait_host(S)
+            la, ga = a.push(pcm[:, :160])                   # and the next full push delivers again
+            a._ctx.sync()
+            assert np.array_equal(ga, a._logits.cpu().numpy())
+            with pytest.raises(ModelError, match="kws_stream_host_results"):
+                b._ctx.stream_wait_host(S)
+            a._ctx.stream_host_results(False)               # switched off: pushes keep working through the device arrays
+            a._host = False
+            la2, ga2 = a.push(pcm[:, 160:320])
+            assert np.isfinite(ga2).all()
+        finally:
+            a.close()
+            b.close()
+
+
 def test_infer_files_of_any_wav_encoding(dev, tmp_path, e2e_golden):
     """inference(wav) on files that are not 16-bit mono PCM: 24-bit and float32 stereo are decoded to float32 mono as
     librosa.load does (load_audio) and take the float32 path (kws_infer_f32); the labels are the oracle's for the same
