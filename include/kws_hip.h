@@ -259,6 +259,12 @@ int kws_stream_cluster(kws_ctx* ctx, int workgroups_per_stream);
  * written.  Call after kws_stream_open and kws_load_dscnn; kws_stream_open / kws_stream_close / enable == 0 release it. */
 int kws_stream_host_results(kws_ctx* ctx, int enable);
 int kws_stream_wait_host(kws_ctx* ctx, const float** h_logits, const int32_t** h_label);
+/* The whole hop from host memory to host memory in one call: h_hop int16 [n_streams, frame_step] (pageable is fine) is copied
+ * into pinned device-mapped memory, the one-launch push reads it from there (no H2D submission), and the call returns when
+ * the kernel has delivered logits [n_streams, C] and labels [n_streams] to the context's host arrays (see above; valid until
+ * the next push).  Enables kws_stream_host_results by itself.  The reference's live path hands a captured utterance to the
+ * model from host memory (kws/inference/inference_local.py:168-192); this is its per-hop counterpart. */
+int kws_stream_push_host_i16(kws_ctx* ctx, const int16_t* h_hop, const float** h_logits, const int32_t** h_label);
 /* Synchronises and returns the feature ring (float32 [n_streams, num_frames, numcep], device memory owned
  * by the context) and the number of pushes so far; the newest frame is row (hops - K) mod num_frames, K = ceil(frame_len / frame_step)
  * hops per frame (3 for the reference's 400 / 160). */

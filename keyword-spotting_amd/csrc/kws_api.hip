@@ -2,6 +2,7 @@
 // weight repacking, workspace and per-kernel event timing.  No torch types, no exceptions across the
 // boundary, no CPU fallback.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -860,6 +861,12 @@ static void host_results_free(kws_ctx* c) {
     if (c->h_stream_logits) (void)hipHostFree(c->h_stream_logits);
     if (c->h_stream_label) (void)hipHostFree(c->h_stream_label);
     if (c->h_stream_flag) (void)hipHostFree(c->h_stream_flag);
+    if (c->h_stream_hop) (void)hipHostFree(c->h_stream_hop);
+    if (c->d_hr_logits) (void)hipFree(c->d_hr_logits);
+    if (c->d_hr_label) (void)hipFree(c->d_hr_label);
+    c->h_stream_hop = nullptr;
+    c->d_hr_logits = nullptr;
+    c->d_hr_label = nullptr;
     c->h_stream_logits = nullptr;
     c->h_stream_label = nullptr;
     c->h_stream_flag = nullptr;
@@ -891,6 +898,7 @@ int kws_stream_open(kws_ctx* c, int n_streams) {
     if (!c->fe_ready) return fail(c, KWS_ESTATE, "kws_stream_open: front end not configured");
     if (!c->fe_fast_ok)
         return fail(c, KWS_EUNSUPPORTED, "kws_stream_open: the streaming frame kernel is built for nfft == 512 and frames of at most 512 samples");
+    if (c->fp.frame_step > 512) return fail(c, KWS_EUNSUPPORTED, "kws_stream_open: hops of more than 512 samples are not supported");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     stream_free(c);
@@ -933,7 +941,10 @@ int kws_stream_host_results(kws_ctx* c, int enable) {
     const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;  // fine-grained: device stores are visible to the host as they land
     if (hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_logits), sizeof(float) * (size_t)c->n_streams * C, flags) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_label), sizeof(int32_t) * (size_t)c->n_streams, flags) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_flag), 64, flags) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_flag), 64, flags) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&c->h_stream_hop), sizeof(int16_t) * (size_t)c->n_streams * c->fp.frame_step, flags) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_hr_logits), sizeof(float) * (size_t)c->n_streams * C) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&c->d_hr_label), sizeof(int32_t) * (size_t)c->n_streams) != hipSuccess) {
         host_results_free(c);
         return fail(c, KWS_ENOMEM, "kws_stream_host_results: pinned host allocation failed");
     }
@@ -958,12 +969,14 @@ int kws_stream_wait_host(kws_ctx* c, const float** h_logits, const int32_t** h_l
     volatile int* flag = c->h_stream_flag;
     const int want = c->host_push;
     bool seen = false;
-    for (long spin = 0; spin < 4000000; ++spin) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 1;; ++spin) {
         if (*flag - want >= 0) {
             seen = true;
             break;
         }
         __builtin_ia32_pause();
+        if ((spin & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     if (!seen) {
         HIP_TRY(c, hipSetDevice(c->device));
@@ -974,6 +987,23 @@ int kws_stream_wait_host(kws_ctx* c, const float** h_logits, const int32_t** h_l
     if (h_logits) *h_logits = c->h_stream_logits;
     if (h_label) *h_label = c->h_stream_label;
     return KWS_OK;
+}
+
+int kws_stream_push_host_i16(kws_ctx* c, const int16_t* h_hop, const float** h_logits, const int32_t** h_label) {
+    if (!c) return KWS_EINVAL;
+    if (!c->n_streams) return fail(c, KWS_ESTATE, "kws_stream_push_host_i16: call kws_stream_open first");
+    if (!h_hop) return fail(c, KWS_EINVAL, "kws_stream_push_host_i16: h_hop is NULL");
+    if (!c->h_stream_flag) {
+        int rc = kws_stream_host_results(c, 1);
+        if (rc) return rc;
+    }
+    // the hop goes into pinned, device-mapped memory and the kernel reads it from there (one PCIe read of 320 bytes per stream
+    // on the frame wavefront's path) -- no H2D submission in front of the launch.  One slot: this call returns after the
+    // kernel's last workgroup has raised the flag, i.e. after every read of it.
+    memcpy(c->h_stream_hop, h_hop, sizeof(int16_t) * (size_t)c->n_streams * c->fp.frame_step);
+    int rc = kws_stream_push_i16(c, c->h_stream_hop, c->d_hr_logits, c->d_hr_label, 0);
+    if (rc) return rc;
+    return kws_stream_wait_host(c, h_logits, h_label);
 }
 
 int kws_stream_cluster(kws_ctx* c, int workgroups_per_stream) {

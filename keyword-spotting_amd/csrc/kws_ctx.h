@@ -63,6 +63,9 @@ struct kws_ctx {
     float* h_stream_logits = nullptr;  // [n_streams][num_classes at enable time]
     int32_t* h_stream_label = nullptr;
     int* h_stream_flag = nullptr;
+    int16_t* h_stream_hop = nullptr;   // [n_streams][frame_step]: the hop of kws_stream_push_host_i16, read by the kernel over PCIe
+    float* d_hr_logits = nullptr;      // device-side outputs of kws_stream_push_host_i16 (the kernel writes both copies)
+    int32_t* d_hr_label = nullptr;
     int host_results_classes = 0;
     int pushes_enqueued = 0;           // pushes since kws_stream_open = the device's hop counter once the stream has drained
     int host_push = 0;                 // the newest push that delivers to host memory (the flag reads this when it is done)

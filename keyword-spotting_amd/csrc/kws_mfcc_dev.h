@@ -703,6 +703,22 @@ __device__ __forceinline__ long stream_frame_wave(const FrontendParams& p, const
     cf v[8];
     bool nza = false, nzb = false;
     float carry_a = 0.f, carry_b = 0.f;  // sample just before this lane block (lane 63 of the previous block)
+    // The hop's copy for the ring append is fetched HERE, together with the frame's own loads, and held in registers: when
+    // the hop lives in pinned host memory (kws_stream_push_host_i16) every dependent load is a PCIe round trip, and this
+    // way the wavefront pays one, not two.
+    int16_t app_a[8], app_b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        app_a[j] = 0;
+        app_b[j] = 0;
+        if (64 * j < step) {  // wave-uniform
+            const int i = 64 * j + lane;
+            if (i < step) {
+                app_a[j] = hop[(size_t)sa * step + i];
+                if (has_b) app_b[j] = hop[(size_t)sb * step + i];
+            }
+        }
+    }
     if (frame_ok) {
         carry_a = sample(sa, d0 - 1);
         if (has_b) carry_b = sample(sb, d0 - 1);
@@ -738,11 +754,15 @@ __device__ __forceinline__ long stream_frame_wave(const FrontendParams& p, const
     // Append the hop to the rings now, so that the stores complete under the transform: the slots they overwrite,
     // [base, base + step) mod ring_len, are older than anything the frame read (the ring is one hop longer than the
     // frame's reach, kws_stream_open), and every read above is earlier in this wavefront's program order.
-    for (int i = lane; i < step; i += 64) {
-        int pos = base_mod + i;
-        pos -= pos >= ring_len ? ring_len : 0;
-        pcm_ring[(size_t)sa * ring_len + pos] = hop[(size_t)sa * step + i];
-        if (has_b) pcm_ring[(size_t)sb * ring_len + pos] = hop[(size_t)sb * step + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = 64 * j + lane;
+        if (64 * j < step && i < step) {
+            int pos = base_mod + i;
+            pos -= pos >= ring_len ? ring_len : 0;
+            pcm_ring[(size_t)sa * ring_len + pos] = app_a[j];
+            if (has_b) pcm_ring[(size_t)sb * ring_len + pos] = app_b[j];
+        }
     }
     wave_lds_order();
     if (frame_ok) {

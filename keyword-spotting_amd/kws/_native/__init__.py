@@ -67,6 +67,7 @@ SIGNATURES = {
     "kws_stream_cluster": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_host_results": (C.c_int, [_c_ctx, C.c_int]),
     "kws_stream_wait_host": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "kws_stream_push_host_i16": (C.c_int, [_c_ctx, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "kws_stream_push_i16": (C.c_int, [_c_ctx, _i16p, _f32p, _i32p, C.c_int]),
     "kws_stream_state": (C.c_int, [_c_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "kws_stream_copy_features": (C.c_int, [_c_ctx, _f32p]),
@@ -337,11 +338,23 @@ class Context:
         self._check(self._lib.kws_stream_host_results(self._h, 1 if enable else 0), ModelError)
         self._host_views = None
 
+    def stream_push_host_i16(self, hop: np.ndarray, n_streams: int):
+        """Host int16 [S, hop] -> (logits, labels) host views in one call (``kws_stream_push_host_i16``): no H2D submission,
+        no synchronise, no D2H copy."""
+        if hop.dtype != np.int16 or not hop.flags.c_contiguous:
+            raise ModelError("stream_push_host_i16 expects a C-contiguous int16 array")
+        pl, py = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.kws_stream_push_host_i16(self._h, hop.ctypes.data, C.byref(pl), C.byref(py)), ModelError)
+        return self._host_views_of(pl, py, n_streams)
+
     def stream_wait_host(self, n_streams: int):
         """Spin until the newest push's results are in host memory; returns numpy VIEWS (logits float32[S,C], labels int32[S])
         of the context's pinned arrays -- valid until the next push."""
         pl, py = C.c_void_p(), C.c_void_p()
         self._check(self._lib.kws_stream_wait_host(self._h, C.byref(pl), C.byref(py)), ModelError)
+        return self._host_views_of(pl, py, n_streams)
+
+    def _host_views_of(self, pl, py, n_streams):
         if getattr(self, "_host_views", None) is None or self._host_views[0] != (pl.value, py.value, n_streams):
             lg = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_float)), shape=(n_streams, self.num_classes))
             lb = np.ctypeslib.as_array(C.cast(py, C.POINTER(C.c_int32)), shape=(n_streams,))

@@ -185,6 +185,14 @@ class StreamingSpotter:
     def push(self, samples) -> Tuple[np.ndarray, np.ndarray]:
         """``int16[n_streams, hop]`` (host array or device tensor) -> (labels int32[S], logits float32[S,C]);
         with ``smooth_window`` > 0 the second array holds the smoothed posteriors and the labels are their argmax."""
+        if self._host and not isinstance(samples, torch.Tensor):
+            # host samples in, host results out, one call: the kernel reads the hop from pinned host memory and writes the
+            # results back there (kws_stream_push_host_i16) -- no H2D copy, no synchronise, no D2H copy
+            h = np.ascontiguousarray(samples, dtype=np.int16)
+            if h.shape != (self.n_streams, self.hop):
+                raise ModelError(f"push expects int16 [{self.n_streams}, {self.hop}]")
+            lg, lb = self._ctx.stream_push_host_i16(h, self.n_streams)
+            return lb.copy(), lg.copy()
         x = samples if isinstance(samples, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(samples, dtype=np.int16))
         if tuple(x.shape) != (self.n_streams, self.hop) or x.dtype != torch.int16:
             raise ModelError(f"push expects int16 [{self.n_streams}, {self.hop}]")

@@ -1532,16 +1532,23 @@ def test_streaming_host_results_are_the_device_results(native, dev, e2e_golden):
         try:
             assert a._host and not b._host
             for t in range(hops):
-                la, ga = a.push(pcm[:, t * 160:(t + 1) * 160])
-                lb, gb = b.push(pcm[:, t * 160:(t + 1) * 160])
+                hop_t = pcm[:, t * 160:(t + 1) * 160]
+                # host samples take kws_stream_push_host_i16 (the kernel reads the hop from pinned host memory), a device
+                # tensor takes kws_stream_push_i16 + kws_stream_wait_host: alternate, the stream state is the same
+                la, ga = a.push(hop_t if t % 2 == 0 else torch.from_numpy(np.ascontiguousarray(hop_t)).to(dev))
+                lb, gb = b.push(hop_t)
                 assert np.array_equal(ga, gb) and np.array_equal(la, lb), (S, t)
-                a._ctx.sync()
-                assert np.array_equal(ga, a._logits.cpu().numpy()) and np.array_equal(la, a._labels.cpu().numpy()), (S, t)
+                if t % 2:
+                    a._ctx.sync()
+                    assert np.array_equal(ga, a._logits.cpu().numpy()) and np.array_equal(la, a._labels.cpu().numpy()), (S, t)
+            fa, na = a.features()
+            fb, nb = b.features()
+            assert na == nb == hops and np.array_equal(fa, fb)
             # a features-only push delivers nothing: the wait says so instead of returning the previous hop's results
             a._ctx.stream_push_i16(a._hop_buf, None, None)
             with pytest.raises(ModelError, match="did not deliver"):
                 a._ctx.stream_wait_host(S)
-            la, ga = a.push(pcm[:, :160])                   # and the next full push delivers again
+            la, ga = a.push(torch.from_numpy(np.ascontiguousarray(pcm[:, :160])).to(dev))  # and the next full push delivers again
             a._ctx.sync()
             assert np.array_equal(ga, a._logits.cpu().numpy())
             with pytest.raises(ModelError, match="kws_stream_host_results"):

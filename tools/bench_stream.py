@@ -64,6 +64,47 @@ def run(S, hops, use_graph, cluster=0, host=False):
     return out
 
 
+def run_host_to_host(S, hops, cluster=0):
+    """The whole hop, host memory to host memory: (a) kws_stream_push_host_i16; (b) what a caller without it does --
+    H2D copy of the hop, push, synchronise, D2H copies of logits and labels."""
+    dev = torch.device("cuda", 0)
+    pcm = np.random.default_rng(0).integers(-32768, 32768, size=(hops, S, 160), dtype=np.int16)
+    out = {}
+    for mode in ("push_host", "copy_push_sync_copy"):
+        ctx = _native.Context(0)
+        ctx.load_dscnn(bench.bench_weights()[0], 12)
+        ctx.stream_open(S)
+        ctx.stream_cluster(cluster)
+        hop = torch.empty((S, 160), dtype=torch.int16, device=dev)
+        logits = torch.empty((S, 12), dtype=torch.float32, device=dev)
+        labels = torch.empty((S,), dtype=torch.int32, device=dev)
+        pin = torch.empty((S, 160), dtype=torch.int16).pin_memory()
+        torch.cuda.synchronize()
+        lat = []
+        for t in range(hops):
+            t0 = time.perf_counter()
+            if mode == "push_host":
+                lg, lb = ctx.stream_push_host_i16(pcm[t], S)
+                res = (lb.copy(), lg.copy())
+            else:
+                pin.numpy()[...] = pcm[t]
+                hop.copy_(pin, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                ctx.stream_push_i16(hop, logits, labels)
+                ctx.sync()
+                res = (labels.cpu().numpy(), logits.cpu().numpy())
+            lat.append((time.perf_counter() - t0) * 1e6)
+        last = res
+        ctx.stream_close(); ctx.close()
+        lat = np.array(lat[min(20, len(lat) // 4):])
+        out[mode] = {"p50_us": float(np.percentile(lat, 50)), "p90_us": float(np.percentile(lat, 90)), "p99_us": float(np.percentile(lat, 99)),
+                     "mean_us": float(lat.mean()), "hops_timed": int(len(lat))}
+        out[mode + "_last"] = last
+    same = bool(np.array_equal(out["push_host_last"][0], out["copy_push_sync_copy_last"][0]) and np.array_equal(out["push_host_last"][1], out["copy_push_sync_copy_last"][1]))
+    return {"push_host": out["push_host"], "copy_push_sync_copy": out["copy_push_sync_copy"], "results_identical": same,
+            "note": "latency = host int16 hop in a numpy array -> labels + logits in numpy arrays (copies included)"}
+
+
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     hops = int(sys.argv[2]) if len(sys.argv) > 2 else 400
@@ -74,6 +115,8 @@ def main():
         out["eager"] = run(S, hops, False, cluster)
     if which in ("host", "both"):
         out["eager_host_results"] = run(S, hops, False, cluster, host=True)
+    if which in ("host", "both"):
+        out["host_to_host"] = run_host_to_host(S, hops, cluster)
     if which in ("hipgraph", "both"):
         out["hipgraph"] = run(S, hops, True, cluster)
     out["real_time_factor_p50"] = 10000.0 / min(v["p50_us"] for k, v in out.items() if k in ("eager", "hipgraph", "eager_host_results"))
