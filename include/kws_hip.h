@@ -291,6 +291,14 @@ int kws_load_cnn_trad(kws_ctx* ctx, const float* blob, size_t n_floats, int num_
 /* float32 [B,1,99,10] features -> logits float32 [B,C] and labels int32 [B] (d_label may be NULL).  The
  * convolution output (76 KB per clip) goes through a context workspace that grows on demand. */
 int kws_forward_cnn_trad_f32(kws_ctx* ctx, const float* d_feat, int B, float* d_logits, int32_t* d_label);
+/* Arithmetic of cnn-trad-fpool3's three GEMM layers on the matrix cores.  KWS_CT_F16_PAIR (default): every f32 operand as an
+ * f16 pair hi + lo' 2^-11 (22 bits) after an exact power-of-two scaling into f16's range -- per layer for the weights, per clip
+ * for the activations from rigorous bounds, so no input can overflow -- three f16 MFMAs per k-block; logits differ from a
+ * float64 evaluation by what a plain f32 evaluation differs by.  KWS_CT_BF16_TRIPLE: the exact three-way bf16 split the DS-CNN
+ * uses (six MFMAs per k-block, twice the matrix time). */
+#define KWS_CT_F16_PAIR 0
+#define KWS_CT_BF16_TRIPLE 1
+int kws_set_cnn_trad_math(kws_ctx* ctx, int math);
 
 /* Fused wav -> label for this model (BASELINE.json configs[2]): kws_mfcc_i16 into the context workspace, then
  * kws_forward_cnn_trad_f32, on the context's stream.  Same arguments and errors as kws_infer_i16. */

@@ -1035,6 +1035,39 @@ static void pack_split8(const float (&v)[8], uint32_t* hi, uint32_t* mid, uint32
     }
 }
 
+// f16-pair pieces of eight weights already multiplied by the layer's power-of-two scale: hi = f16(v) (round to nearest),
+// lo' = f16((v - hi) * 2^11); OR-ed into four dwords per piece like pack_split8 (kws_cnntrad.hip, split_pair).
+static void pack_pair8(const float (&v)[8], float scale, uint32_t* hi, uint32_t* lo) {
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * scale;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)((x - (float)h) * 2048.f);
+        uint16_t hb, lb;
+        memcpy(&hb, &h, 2);
+        memcpy(&lb, &l, 2);
+        hi[j >> 1] |= (uint32_t)hb << (16 * (j & 1));
+        lo[j >> 1] |= (uint32_t)lb << (16 * (j & 1));
+    }
+}
+// the power of two s with max|w| * s < 2^15, and the layer's bound terms
+static float pow2_weight_scale(const float* w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+    if (!(m > 0.f) || !std::isfinite(m)) return 1.f;
+    int e;
+    (void)std::frexp(m, &e);  // m = f * 2^e, f in [0.5, 1): m < 2^e
+    return std::ldexp(1.f, std::max(-100, std::min(100, 15 - e)));
+}
+static float max_row_abs_sum(const float* w, int rows, size_t row_len) {
+    double best = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        double a = 0.0;
+        for (size_t i = 0; i < row_len; ++i) a += std::fabs((double)w[(size_t)r * row_len + i]);
+        best = std::max(best, a);
+    }
+    return (float)(best * 1.0000002);  // rounded up
+}
+
 int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_classes) {
     KWS_GUARD_BEGIN
     if (!c) return KWS_EINVAL;
@@ -1053,8 +1086,12 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     // device image (units: 32-bit words): c1_split | c2_split | c1_b | c2_b | lin_split | lin_b | dnn_w | dnn_b | fc_w | fc_b
     const size_t o_c1s = 0, o_c2s = o_c1s + 10 * 2 * 3 * 64 * 4, o_c1b = o_c2s + (size_t)40 * 4 * 2 * 3 * 64 * 4, o_c2b = o_c1b + 64,
                  o_lin = o_c2b + 64, o_linb = o_lin + (size_t)(FLAT / 16) * 3 * 64 * 4, o_dnn = o_linb + 32, o_dnnb = o_dnn + n_dnn, o_fc = o_dnnb + 128,
-                 o_fcb = o_fc + n_fc, total = o_fcb + num_classes;
+                 o_fcb = o_fc + n_fc,
+                 // f16-pair images (two pieces), 16-byte aligned
+                 o_c1h = (o_fcb + num_classes + 3) / 4 * 4, o_c2h = o_c1h + 10 * 2 * 2 * 64 * 4, o_linh = o_c2h + (size_t)40 * 4 * 2 * 2 * 64 * 4,
+                 total = o_linh + (size_t)(FLAT / 16) * 2 * 64 * 4;
     std::vector<uint32_t> h(total, 0u);
+    const float sw1 = pow2_weight_scale(w1, n_c1), sw2 = pow2_weight_scale(w2, n_c2), swl = pow2_weight_scale(wl, n_lin);
     auto put = [&](size_t off, const float* src, size_t n) { memcpy(&h[off], src, n * sizeof(float)); };
     // conv1: lane l of (kb, ct): cout = 32ct + (l&31), kernel row 2kb + (l>>5), kernel columns j = 0..7
     for (int kb = 0; kb < 10; ++kb)
@@ -1065,6 +1102,8 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                 for (int j = 0; j < 8; ++j) v[j] = w1[(co * 20 + kh) * 8 + j];
                 uint32_t* base = &h[o_c1s + ((size_t)(kb * 2 + ct) * 3 * 64 + l) * 4];
                 pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+                uint32_t* b2 = &h[o_c1h + ((size_t)(kb * 2 + ct) * 2 * 64 + l) * 4];
+                pack_pair8(v, sw1, b2, b2 + 64 * 4);
             }
     // conv2: lane l of (kk = kh*4 + kw, cb, ct): cout = 32ct + (l&31), input channels 16cb + 8(l>>5) + j
     for (int kk = 0; kk < 40; ++kk)
@@ -1076,6 +1115,8 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                     for (int j = 0; j < 8; ++j) v[j] = w2[((co * 64 + 16 * cb + 8 * (l >> 5) + j) * 10 + kh) * 4 + kw];
                     uint32_t* base = &h[o_c2s + ((((size_t)kk * 4 + cb) * 2 + ct) * 3 * 64 + l) * 4];
                     pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+                    uint32_t* b2 = &h[o_c2h + ((((size_t)kk * 4 + cb) * 2 + ct) * 2 * 64 + l) * 4];
+                    pack_pair8(v, sw2, b2, b2 + 64 * 4);
                 }
     put(o_c1b, b1, 64);
     put(o_c2b, b2, 64);
@@ -1086,6 +1127,8 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
             for (int j = 0; j < 8; ++j) v[j] = wl[(size_t)(l & 31) * FLAT + 16 * kb + 8 * (l >> 5) + j];
             uint32_t* base = &h[o_lin + (kb * 3 * 64 + l) * 4];
             pack_split8(v, base, base + 64 * 4, base + 2 * 64 * 4);
+            uint32_t* b2 = &h[o_linh + (kb * 2 * 64 + l) * 4];
+            pack_pair8(v, swl, b2, b2 + 64 * 4);
         }
     put(o_linb, bl, 32);
     put(o_dnn, wd, n_dnn);
@@ -1117,6 +1160,20 @@ int kws_load_cnn_trad(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->tw.fc_w = df + o_fc;
     c->tw.fc_b = df + o_fcb;
     c->tw.num_classes = num_classes;
+    c->tw.c1_h2 = d + o_c1h;
+    c->tw.c2_h2 = d + o_c2h;
+    c->tw.lin_h2 = d + o_linh;
+    c->tw.inv_sw1 = 1.f / sw1;
+    c->tw.inv_sw2 = 1.f / sw2;
+    c->tw.inv_swl = 1.f / swl;
+    c->tw.w1_abs = max_row_abs_sum(w1, 64, 160);
+    c->tw.w2_abs = max_row_abs_sum(w2, 64, 2560);
+    c->tw.b1_max = 0.f;
+    c->tw.b2_max = 0.f;
+    for (int i = 0; i < 64; ++i) {
+        c->tw.b1_max = std::max(c->tw.b1_max, std::fabs(b1[i]));
+        c->tw.b2_max = std::max(c->tw.b2_max, std::fabs(b2[i]));
+    }
     c->cnntrad_ready = true;
     return KWS_OK;
     KWS_GUARD_END(c, "kws_load_cnn_trad")
@@ -1161,16 +1218,24 @@ int kws_forward_cnn_trad_f32(kws_ctx* c, const float* d_feat, int B, float* d_lo
     if (!d_logits) return fail(c, KWS_EINVAL, "kws_forward_cnn_trad_f32: d_logits is NULL");
     if (!c->cnntrad_ready) return fail(c, KWS_ESTATE, "kws_forward_cnn_trad_f32: no model loaded (kws_load_cnn_trad)");
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = grow_conv_ws(c, (size_t)B * 64 * 297, "kws_forward_cnn_trad_f32");
+    rc = grow_conv_ws(c, (size_t)B * 64 * 297 + (size_t)B, "kws_forward_cnn_trad_f32");  // + one scale per clip (f16-pair arithmetic)
     if (rc) return rc;
+    const bool pair = c->cnntrad_math == KWS_CT_F16_PAIR;
     {
         ProfScope ps(c, KWS_K_CNNTRAD_CONV);
-        HIP_TRY(c, launch_cnntrad_conv(c->stream, c->tw, d_feat, B, c->d_conv_ws));
+        HIP_TRY(c, launch_cnntrad_conv(c->stream, c->tw, d_feat, B, c->d_conv_ws, pair));
     }
     {
         ProfScope ps(c, KWS_K_CNNTRAD_DENSE);
-        HIP_TRY(c, launch_cnntrad_dense(c->stream, c->tw, c->d_conv_ws, B, d_logits, d_label));
+        HIP_TRY(c, launch_cnntrad_dense(c->stream, c->tw, c->d_conv_ws, B, d_logits, d_label, pair));
     }
+    return KWS_OK;
+}
+
+int kws_set_cnn_trad_math(kws_ctx* c, int math) {
+    if (!c) return KWS_EINVAL;
+    if (math != KWS_CT_F16_PAIR && math != KWS_CT_BF16_TRIPLE) return fail(c, KWS_EINVAL, "kws_set_cnn_trad_math: unknown arithmetic");
+    c->cnntrad_math = math;
     return KWS_OK;
 }
 

@@ -48,22 +48,102 @@ static_assert(XP_H * XP_W * 4 <= XP_BYTES, "padded input does not fit its LDS sl
 
 __device__ __forceinline__ float lane_up(float v) { return from_lane_above(v); }
 
+// ---- f16-pair arithmetic (H2 = true, the default; kws_set_cnn_trad_math) ----------------------------------------
+// Every f32 GEMM operand v, first scaled by a power of two s into f16's range, is written as hi + lo' * 2^-11 with
+// hi = f16(v s) (round to nearest) and lo' = f16((v s - hi) * 2^11): 22 significant bits.  f16 x f16 products are exact in
+// the matrix core's f32 accumulate; hi*hi goes to one accumulator, hi*lo' + lo'*hi to a second one that is scaled by
+// 2^-11 at the end (the dropped lo*lo term is <= 2^-22 of the product).  THREE v_mfma_f32_32x32x16_f16 per f32 k-block
+// instead of the six bf16 ones of the three-way split, two operand pieces to load instead of three -- this model is
+// bound by the matrix pipe, so that is the lever -- for logits that differ from float64 by what torch's own f32 forward
+// differs by (tools/cnntrad_f16_pair_sim.py).  Range: weights are scaled per layer at load time so that max |w| s < 2^15;
+// activations per CLIP, from rigorous bounds known before the values exist: M0 = max |feature| of the clip (measured
+// while staging), |conv1 out| <= max_c sum|w1[c]| M0 + max|b1|, |conv2 out| <= max_c sum|w2[c]| * that + max|b2|.  The
+// bounds are loose by 2^4..2^7 per layer; f16 keeps 11 bits down to 2^-14 and the scaled values top out below 2^15, so a
+// value keeps full relative precision down to 2^-29 of its layer's bound and an absolute 2^-40 of it below that: no
+// overflow for any input, no precision cliff.  All scalings are by powers of two (exact).
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx16 mfma_f16(const uintx4& a, const uintx4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split_pair(float even, float odd, uint32_t& hi, uint32_t& lo) {
+    const halfx2 h = {(_Float16)even, (_Float16)odd};
+    const halfx2 l = {(_Float16)((even - (float)h[0]) * 2048.f), (_Float16)((odd - (float)h[1]) * 2048.f)};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ void split2(const float (&y)[8], uintx4& hi, uintx4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t h, l;
+        split_pair(y[2 * i], y[2 * i + 1], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+constexpr float LO_UNSCALE = 1.f / 2048.f;
+// the power of two s with bound * s < 2^15 (bound >= 0; exponent kept within +-100 so that 1/s is a normal float too)
+__device__ __forceinline__ int pow2_exp_for(float bound) {
+    const int e = (int)((__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu);  // bound < 2^(e - 126)
+    const int k = 141 - e;
+    return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23); }
+
+template <bool H2>
 __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights w, const float* __restrict__ feat, int B,
-                                                                 float* __restrict__ conv_out) {
+                                                                 float* __restrict__ conv_out, float* __restrict__ clip_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t m0_bits;
     float* xp = reinterpret_cast<float*>(smem);
     unsigned char* planes = smem + XP_BYTES;
+    constexpr int NP = H2 ? 2 : 3;  // operand pieces
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
     const int clip = blockIdx.x;
     if (clip >= B) return;
 
     // ---- stage: zero-padded input map, zero regions of the pooled planes ---------------------------------
     for (int i = tid; i < XP_H * XP_W; i += CT_NT) xp[i] = 0.f;
-    if (tid < 3 * PL_ZERO_BYTES / 4)
+    if (tid < NP * PL_ZERO_BYTES / 4)
         reinterpret_cast<uint32_t*>(planes + (tid / (PL_ZERO_BYTES / 4)) * PLANE_BYTES + PL_ZERO_OFF)[tid % (PL_ZERO_BYTES / 4)] = 0u;
+    if (tid == 0) m0_bits = 0u;
     __syncthreads();
-    for (int i = tid; i < CT_T * CT_F; i += CT_NT)
-        xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = feat[(size_t)clip * (CT_T * CT_F) + i];
+    // H2: per-clip scales.  post1 / post2 take a layer's accumulators back to true units, s1 maps the pooled conv1 output
+    // into f16's range (see the note at split_pair)
+    float post1 = 1.f, post2 = 1.f, s1 = 1.f;
+    if constexpr (H2) {
+        float v[2] = {0.f, 0.f}, mx = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int i = tid + n * CT_NT;
+            if (i < CT_T * CT_F) {
+                v[n] = feat[(size_t)clip * (CT_T * CT_F) + i];
+                mx = fmaxf(mx, fabsf(v[n]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) atomicMax(&m0_bits, __builtin_bit_cast(uint32_t, mx));  // non-negative floats order like their bits
+        __syncthreads();
+        const float m0 = __builtin_bit_cast(float, m0_bits);
+        const int k0 = pow2_exp_for(m0);
+        const float bound1 = (w.w1_abs * m0 + w.b1_max) * 1.001f;
+        const float bound2 = (w.w2_abs * bound1 + w.b2_max) * 1.001f;
+        const int k1 = pow2_exp_for(bound1), k2 = pow2_exp_for(bound2);
+        post1 = pow2f(-k0) * w.inv_sw1;
+        s1 = pow2f(k1);
+        post2 = pow2f(-k1) * w.inv_sw2;
+        if (tid == 0) clip_scale[clip] = pow2f(k2);
+        const float s0 = pow2f(k0);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int i = tid + n * CT_NT;
+            if (i < CT_T * CT_F) xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = v[n] * s0;
+        }
+    } else {
+        for (int i = tid; i < CT_T * CT_F; i += CT_NT)
+            xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = feat[(size_t)clip * (CT_T * CT_F) + i];
+    }
     __syncthreads();
 
     // ---- conv1 + ReLU + frequency max-pool -> pre-split planes ------------------------------------------
@@ -73,13 +153,13 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
     // whole phase -- streamed per tile they would cost 2 MB of L1 traffic per clip -- and walks tiles w>>1, +4, ...
     {
         const int ct = wv & 1;
-        uintx4 af[CT_K1H / 2][3];  // [k-block][piece]
+        uintx4 af[CT_K1H / 2][NP];  // [k-block][piece]
         {
-            const uintx4* asrc = reinterpret_cast<const uintx4*>(w.c1_split) + ct * (3 * 64) + lane;
+            const uintx4* asrc = reinterpret_cast<const uintx4*>(H2 ? w.c1_h2 : w.c1_split) + ct * (NP * 64) + lane;
 #pragma unroll
             for (int kb = 0; kb < CT_K1H / 2; ++kb)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) af[kb][pc] = asrc[(kb * 2 * 3 + pc) * 64];
+                for (int pc = 0; pc < NP; ++pc) af[kb][pc] = asrc[(kb * 2 * NP + pc) * 64];
         }
         float bias[16];
 #pragma unroll
@@ -101,18 +181,30 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
 #pragma unroll
             for (int kb = 0; kb < CT_K1H / 2; ++kb) {
                 const int cur = kb & 1;
-                uintx4 bh, bm, bl;
-                split3(y[cur], bh, bm, bl);
-                if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
-                // six piece products, smallest first
-                acc = mfma_bf16(af[kb][2], bh, acc);
-                acc2 = mfma_bf16(af[kb][0], bl, acc2);
-                acc = mfma_bf16(af[kb][1], bm, acc);
-                acc2 = mfma_bf16(af[kb][1], bh, acc2);
-                acc = mfma_bf16(af[kb][0], bm, acc);
-                acc2 = mfma_bf16(af[kb][0], bh, acc2);
+                if constexpr (H2) {  // acc = hi * hi, acc2 = the cross terms (in units of 2^-11)
+                    uintx4 bh, bl;
+                    split2(y[cur], bh, bl);
+                    if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
+                    acc2 = mfma_f16(af[kb][0], bl, acc2);
+                    acc = mfma_f16(af[kb][0], bh, acc);
+                    acc2 = mfma_f16(af[kb][NP - 1], bh, acc2);
+                } else {
+                    uintx4 bh, bm, bl;
+                    split3(y[cur], bh, bm, bl);
+                    if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
+                    // six piece products, smallest first
+                    acc = mfma_bf16(af[kb][NP - 1], bh, acc);
+                    acc2 = mfma_bf16(af[kb][0], bl, acc2);
+                    acc = mfma_bf16(af[kb][1], bm, acc);
+                    acc2 = mfma_bf16(af[kb][1], bh, acc2);
+                    acc = mfma_bf16(af[kb][0], bm, acc);
+                    acc2 = mfma_bf16(af[kb][0], bh, acc2);
+                }
             }
-            acc += acc2;
+            if constexpr (H2)
+                acc = (acc + acc2 * LO_UNSCALE) * post1;
+            else
+                acc += acc2;
             // bias, ReLU, max over bins (f, f+1, f+2) via two lane shifts; lanes with f in {0,3,6} own a pooled value
             const int p = t * CT_FP + f / 3;
 #pragma unroll
@@ -126,11 +218,18 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                 }
                 if (owner) {  // channels co, co+1 (co even) as one dword per piece
                     const int co = ct * 32 + row_of(r, half);
-                    const float r0 = m[0] - top16(m[0]), r1 = m[1] - top16(m[1]);
                     uint32_t* dst = reinterpret_cast<uint32_t*>(planes + p * PL_STRIDE + co * 2);
-                    dst[0] = pack_top16(m[0], m[1]);
-                    dst[PLANE_BYTES / 4] = pack_top16(r0, r1);
-                    dst[2 * PLANE_BYTES / 4] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+                    if constexpr (H2) {
+                        uint32_t hi, lo;
+                        split_pair(m[0] * s1, m[1] * s1, hi, lo);
+                        dst[0] = hi;
+                        dst[PLANE_BYTES / 4] = lo;
+                    } else {
+                        const float r0 = m[0] - top16(m[0]), r1 = m[1] - top16(m[1]);
+                        dst[0] = pack_top16(m[0], m[1]);
+                        dst[PLANE_BYTES / 4] = pack_top16(r0, r1);
+                        dst[2 * PLANE_BYTES / 4] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+                    }
                 }
             }
         }
@@ -147,10 +246,12 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
     // k-block for all of the wavefront's tiles.
     auto conv2_unit = [&](auto ntile_tag, int tile0) {
         constexpr int NTILE = decltype(ntile_tag)::value;
+        constexpr int NACC = H2 ? 2 : 1;       // H2: [0] = hi * hi, [1] = cross terms in units of 2^-11
+        constexpr int NPROD = H2 ? 3 : 6;      // piece products per k-block
         const int ct = wv & 1;
         int p[NTILE], t[NTILE], fp[NTILE];
         bool pvalid[NTILE];
-        floatx16 acc[NTILE];
+        floatx16 acc[NTILE][NACC];
 #pragma unroll
         for (int i = 0; i < NTILE; ++i) {
             p[i] = (tile0 + i) * 32 + col;
@@ -158,17 +259,20 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
             t[i] = p[i] / CT_FP;  // columns past the map keep their natural geometry: they read zeros from their own bank slot
             fp[i] = p[i] % CT_FP;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][a][r] = 0.f;
         }
-        const uintx4* asrc = reinterpret_cast<const uintx4*>(w.c2_split) + ct * (3 * 64) + lane;
+        const uintx4* asrc = reinterpret_cast<const uintx4*>(H2 ? w.c2_h2 : w.c2_split) + ct * (NP * 64) + lane;
         // Pipeline at k-block granularity: the A operands of (kk+1, cb) are requested right after those of (kk, cb)
         // have been used (four k-blocks ahead of their use, an L2 round trip); the B operands of the next k-block
         // are read from LDS one k-block ahead.
-        uintx4 af[4][3];         // [cb][piece] of this wavefront's channel tile
-        uintx4 bf[2][NTILE][3];  // [parity of the k-block][tile][piece]
+        uintx4 af[4][NP];         // [cb][piece] of this wavefront's channel tile
+        uintx4 bf[2][NTILE][NP];  // [parity of the k-block][tile][piece]
+        auto a_index = [&](int kk, int cb, int pc2) { return (((size_t)kk * 4 + cb) * 2 * NP + pc2) * 64; };
         auto a_load = [&](int kk, int cb) {
 #pragma unroll
-            for (int pc2 = 0; pc2 < 3; ++pc2) af[cb][pc2] = asrc[(((size_t)kk * 4 + cb) * 2 * 3 + pc2) * 64];
+            for (int pc2 = 0; pc2 < NP; ++pc2) af[cb][pc2] = asrc[a_index(kk, cb, pc2)];
         };
         auto b_addr = [&](int kk, int i) -> const unsigned char* {
             const int kh = kk >> 2, kw = kk & 3;
@@ -177,11 +281,11 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
             const int natural = (tin * CT_FP + fin) * PL_STRIDE + half * 16;  // may lie outside the plane
             return planes + (ok ? natural : PL_ZERO_OFF + (natural & 255));
         };
-        auto b_load = [&](const unsigned char* const (&ba)[NTILE], int cb, uintx4 (&dst)[NTILE][3]) {
+        auto b_load = [&](const unsigned char* const (&ba)[NTILE], int cb, uintx4 (&dst)[NTILE][NP]) {
 #pragma unroll
             for (int i = 0; i < NTILE; ++i)
 #pragma unroll
-                for (int pc2 = 0; pc2 < 3; ++pc2) dst[i][pc2] = *reinterpret_cast<const uintx4*>(ba[i] + cb * 32 + pc2 * PLANE_BYTES);
+                for (int pc2 = 0; pc2 < NP; ++pc2) dst[i][pc2] = *reinterpret_cast<const uintx4*>(ba[i] + cb * 32 + pc2 * PLANE_BYTES);
         };
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) a_load(0, cb);
@@ -200,25 +304,31 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                 // The loads of the next k-block are spread between the MFMAs (one load behind each matrix
                 // instruction, pinned with scheduling barriers): issued in a lump after them, the matrix pipe drains
                 // while the wavefront works through a dozen memory instructions.  An A piece is re-requested for
-                // (kk+1, cb) right behind its last use: lo after product 0, mid after product 3, hi after product 5.
+                // (kk+1, cb) right behind its last use.
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {  // six piece products, smallest first, tiles interleaved
-                    const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-                    const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
+                for (int q = 0; q < NPROD; ++q) {  // piece products, smallest first, tiles interleaved
+                    // three-way bf16: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); f16 pair: (hi,lo') (hi,hi) (lo',hi)
+                    const int pa = H2 ? (q == 2 ? 1 : 0) : (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0);
+                    const int pb = H2 ? (q == 0 ? 1 : 0) : ((q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1));
+                    const int dst = H2 ? (q == 1 ? 0 : 1) : 0;
 #pragma unroll
                     for (int i = 0; i < NTILE; ++i) {
-                        acc[i] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i]);
+                        if constexpr (H2)
+                            acc[i][dst] = mfma_f16(af[cb][pa], bf[cur][i][pb], acc[i][dst]);
+                        else
+                            acc[i][dst] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i][dst]);
                         __builtin_amdgcn_sched_barrier(0);
-                        const int n = q * NTILE + i;  // one B load (tile n / 3, piece n % 3) of the next k-block per MFMA
-                        if (n < 3 * NTILE) {
-                            const unsigned char* src = (cb < 3 ? ba[n / 3] + (cb + 1) * 32 : ba_next[n / 3]) + (n % 3) * PLANE_BYTES;
-                            bf[cur ^ 1][n / 3][n % 3] = *reinterpret_cast<const uintx4*>(src);
+                        const int n = q * NTILE + i;  // one B load (tile n / NP, piece n % NP) of the next k-block per MFMA
+                        if (n < NP * NTILE) {
+                            const unsigned char* src = (cb < 3 ? ba[n / NP] + (cb + 1) * 32 : ba_next[n / NP]) + (n % NP) * PLANE_BYTES;
+                            bf[cur ^ 1][n / NP][n % NP] = *reinterpret_cast<const uintx4*>(src);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                    if (more && (q == 0 || q == 3 || q == 5)) {
-                        const int pc2 = q == 0 ? 2 : q == 3 ? 1 : 0;
-                        af[cb][pc2] = asrc[(((size_t)(kk + 1) * 4 + cb) * 2 * 3 + pc2) * 64];
+                    // last use of an A piece: three-way lo after product 0, mid after 3, hi after 5; pair hi after 1, lo' after 2
+                    const int done = H2 ? (q == 1 ? 0 : (q == 2 ? 1 : -1)) : (q == 0 ? 2 : (q == 3 ? 1 : (q == 5 ? 0 : -1)));
+                    if (more && done >= 0) {
+                        af[cb][done] = asrc[a_index(kk + 1, cb, done)];
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -233,7 +343,9 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = ct * 32 + row_of(r, half);
-                    o[co * CT_P2] = relu(acc[i][r] + w.c2_b[co]);
+                    float v = acc[i][0][r];
+                    if constexpr (H2) v = (v + acc[i][NACC - 1][r] * LO_UNSCALE) * post2;
+                    o[co * CT_P2] = relu(v + w.c2_b[co]);
                 }
             }
         }
@@ -257,8 +369,11 @@ constexpr int CT_LIN = 32, CT_DNN = 128;
 constexpr int DN_WAVES = 12, DN_KB = CT_FLAT / 16 / DN_WAVES;  // 99 k-blocks per wavefront
 constexpr int DN_CLIPS = 16;  // clips per workgroup: 4096 clips = 256 workgroups, one per CU (32 leaves half the CUs idle: 2.31 vs 2.27 ms for the model; 8 is slower again, 2.36)
 static_assert(DN_KB * DN_WAVES * 16 == CT_FLAT, "K must divide evenly among the wavefronts");
-__global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTradWeights w, const float* __restrict__ conv_out, int B,
+template <bool H2>
+__global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTradWeights w, const float* __restrict__ conv_out,
+                                                                          const float* __restrict__ clip_scale, int B,
                                                                           float* __restrict__ logits, int32_t* __restrict__ label) {
+    constexpr int NP = H2 ? 2 : 3;
     __shared__ float part[DN_WAVES][32 * 32];  // partial D of every wavefront, [clip][output]
     __shared__ float h1[32][CT_LIN];
     __shared__ float h2[32][CT_DNN];
@@ -272,16 +387,17 @@ __global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTra
         const int aclip = clip0 + aslot < B ? clip0 + aslot : B - 1;
         const float4* xa = reinterpret_cast<const float4*>(conv_out + (size_t)aclip * CT_FLAT + (size_t)wv * DN_KB * 16 + 8 * half);
         // B operand: pre-split weights [kb][piece][lane]
-        const uintx4* wb = reinterpret_cast<const uintx4*>(w.lin_split) + (size_t)wv * DN_KB * 3 * 64 + lane;
-        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uintx4* wb = reinterpret_cast<const uintx4*>(H2 ? w.lin_h2 : w.lin_split) + (size_t)wv * DN_KB * NP * 64 + lane;
+        floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, accx = acc;
+        const float s2 = H2 ? clip_scale[aclip] : 1.f;  // H2: the clip's power-of-two scale into f16's range (written by the conv kernel)
         constexpr int DEPTH = 3;
         float4 xr[DEPTH][2];
-        uintx4 wr[DEPTH][3];
+        uintx4 wr[DEPTH][NP];
         auto load = [&](int kb, int slot) {
             xr[slot][0] = xa[kb * 4];
             xr[slot][1] = xa[kb * 4 + 1];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) wr[slot][pc] = wb[(kb * 3 + pc) * 64];
+            for (int pc = 0; pc < NP; ++pc) wr[slot][pc] = wb[(kb * NP + pc) * 64];
         };
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) load(d, d);
@@ -289,27 +405,44 @@ __global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTra
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const int kb = kb0 + d;
-                const float y[8] = {xr[d][0].x, xr[d][0].y, xr[d][0].z, xr[d][0].w, xr[d][1].x, xr[d][1].y, xr[d][1].z, xr[d][1].w};
-                uintx4 ah, am, al;
-                split3(y, ah, am, al);
-                const uintx4 bh = wr[d][0], bm = wr[d][1], bl = wr[d][2];
-                if (kb + DEPTH < DN_KB) load(kb + DEPTH, d);
-                acc = mfma_bf16(al, bh, acc);
-                acc = mfma_bf16(ah, bl, acc);
-                acc = mfma_bf16(am, bm, acc);
-                acc = mfma_bf16(am, bh, acc);
-                acc = mfma_bf16(ah, bm, acc);
-                acc = mfma_bf16(ah, bh, acc);
+                if constexpr (H2) {
+                    const float y[8] = {xr[d][0].x * s2, xr[d][0].y * s2, xr[d][0].z * s2, xr[d][0].w * s2,
+                                        xr[d][1].x * s2, xr[d][1].y * s2, xr[d][1].z * s2, xr[d][1].w * s2};
+                    uintx4 ah, al;
+                    split2(y, ah, al);
+                    const uintx4 bh = wr[d][0], bl = wr[d][NP - 1];
+                    if (kb + DEPTH < DN_KB) load(kb + DEPTH, d);
+                    accx = mfma_f16(ah, bl, accx);
+                    acc = mfma_f16(ah, bh, acc);
+                    accx = mfma_f16(al, bh, accx);
+                } else {
+                    const float y[8] = {xr[d][0].x, xr[d][0].y, xr[d][0].z, xr[d][0].w, xr[d][1].x, xr[d][1].y, xr[d][1].z, xr[d][1].w};
+                    uintx4 ah, am, al;
+                    split3(y, ah, am, al);
+                    const uintx4 bh = wr[d][0], bm = wr[d][1], bl = wr[d][NP - 1];
+                    if (kb + DEPTH < DN_KB) load(kb + DEPTH, d);
+                    acc = mfma_bf16(al, bh, acc);
+                    acc = mfma_bf16(ah, bl, acc);
+                    acc = mfma_bf16(am, bm, acc);
+                    acc = mfma_bf16(am, bh, acc);
+                    acc = mfma_bf16(ah, bm, acc);
+                    acc = mfma_bf16(ah, bh, acc);
+                }
             }
         }
+        if constexpr (H2) acc += accx * LO_UNSCALE;
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[wv][row_of(r, half) * 32 + col] = acc[r];  // D row = clip slot, column = output
     }
     __syncthreads();
     for (int i = tid; i < DN_CLIPS * CT_LIN; i += DN_WAVES * 64) {
-        float a = w.lin_b[i & 31];
+        float a = H2 ? 0.f : w.lin_b[i & 31];
 #pragma unroll
         for (int k = 0; k < DN_WAVES; ++k) a += part[k][i];
+        if constexpr (H2) {  // back to true units: the clip's scale and the layer's weight scale are powers of two
+            const int cl = clip0 + (i >> 5) < B ? clip0 + (i >> 5) : B - 1;
+            a = a * (w.inv_swl / clip_scale[cl]) + w.lin_b[i & 31];
+        }
         h1[i >> 5][i & 31] = a;
     }
     __syncthreads();
@@ -343,19 +476,34 @@ __global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTra
 
 }  // namespace
 
+constexpr int CT_LDS_BYTES_H2 = XP_BYTES + 2 * PLANE_BYTES;
+
 hipError_t cnntrad_init_device() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kws_cnntrad_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               CT_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kws_cnntrad_conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       CT_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kws_cnntrad_conv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               CT_LDS_BYTES_H2);
 }
 
-hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws) {
-    hipLaunchKernelGGL(kws_cnntrad_conv_kernel, dim3(B), dim3(CT_NT), CT_LDS_BYTES, s, w, d_feat, B, d_conv_ws);
+// d_conv_ws: B * 19008 floats of conv2 output, then B floats of per-clip scales (f16-pair arithmetic only)
+hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, bool f16_pair) {
+    float* scale = d_conv_ws + (size_t)B * CT_FLAT;
+    if (f16_pair)
+        hipLaunchKernelGGL(kws_cnntrad_conv_kernel<true>, dim3(B), dim3(CT_NT), CT_LDS_BYTES_H2, s, w, d_feat, B, d_conv_ws, scale);
+    else
+        hipLaunchKernelGGL(kws_cnntrad_conv_kernel<false>, dim3(B), dim3(CT_NT), CT_LDS_BYTES, s, w, d_feat, B, d_conv_ws, scale);
     return hipGetLastError();
 }
 
 hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const float* d_conv_ws, int B, float* d_logits,
-                                int32_t* d_label) {
-    hipLaunchKernelGGL(kws_cnntrad_dense_kernel, dim3((B + DN_CLIPS - 1) / DN_CLIPS), dim3(DN_WAVES * 64), 0, s, w, d_conv_ws, B, d_logits, d_label);
+                                int32_t* d_label, bool f16_pair) {
+    const float* scale = d_conv_ws + (size_t)B * CT_FLAT;
+    const dim3 grid((B + DN_CLIPS - 1) / DN_CLIPS), block(DN_WAVES * 64);
+    if (f16_pair)
+        hipLaunchKernelGGL(kws_cnntrad_dense_kernel<true>, grid, block, 0, s, w, d_conv_ws, scale, B, d_logits, d_label);
+    else
+        hipLaunchKernelGGL(kws_cnntrad_dense_kernel<false>, grid, block, 0, s, w, d_conv_ws, scale, B, d_logits, d_label);
     return hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ struct kws_ctx {
     void* d_cnntrad = nullptr;
     CnnTradWeights tw{};
     bool cnntrad_ready = false;
+    int cnntrad_math = KWS_CT_F16_PAIR;
     float* d_conv_ws = nullptr;
     size_t conv_ws_floats = 0;
 

@@ -194,11 +194,19 @@ struct CnnTradWeights {
     const float* fc_w;         // [C][128]
     const float* fc_b;         // [C]
     int num_classes;
+    // f16-pair arithmetic (kws_cnntrad.hip): every weight scaled by the layer's power of two sw (max |w| sw < 2^15) and written
+    // as hi = f16(w sw), lo' = f16((w sw - hi) 2^11); same fragment orders as above with two pieces
+    const uint32_t* c1_h2;     // [kb 10][ct 2][piece 2][lane 64][4]
+    const uint32_t* c2_h2;     // [kk 40][cb 4][ct 2][piece 2][lane 64][4]
+    const uint32_t* lin_h2;    // [kb 1188][piece 2][lane 64][4]
+    float inv_sw1, inv_sw2, inv_swl;   // 1 / sw per layer
+    float w1_abs, b1_max;      // max over output channels of sum |w1[c]|, max |b1|: |conv1 out| <= w1_abs * max|x| + b1_max
+    float w2_abs, b2_max;      // the same for conv2
 };
 hipError_t cnntrad_init_device();
-hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws);
+hipError_t launch_cnntrad_conv(hipStream_t s, const CnnTradWeights& w, const float* d_feat, int B, float* d_conv_ws, bool f16_pair);
 hipError_t launch_cnntrad_dense(hipStream_t s, const CnnTradWeights& w, const float* d_conv_ws, int B, float* d_logits,
-                                int32_t* d_label);
+                                int32_t* d_label, bool f16_pair);
 
 // Standalone depthwise-separable block on an arbitrary [B, C_in, H, W] map (kws_dsblock.hip); d_ws: B*C_in*Ho*Wo floats.
 hipError_t launch_dsblock(hipStream_t s, const float* d_x, int B, int C_in, int H, int W, const float* d_dw_w, const float* d_dw_b,

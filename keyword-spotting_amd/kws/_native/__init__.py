@@ -19,6 +19,7 @@ from kws.common.errors import AudioProcessingError, KWSError, ModelError
 LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkws_hip.so")
 
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+KWS_CT_F16_PAIR, KWS_CT_BF16_TRIPLE = 0, 1  # kws_set_cnn_trad_math
 KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME, KWS_K_MFCC_F64, KWS_K_MFCC_REFINE = 0, 1, 2, 3, 4, 5, 6
 FE_REFINE_SPAN_DEFAULT = 12.0  # KWS_FE_REFINE_SPAN_DEFAULT: log-mel span beyond which a frame is redone in float64
 FE_F32, FE_F64 = 0, 1  # KWS_FE_F32 (default: the fast float32 front end) / KWS_FE_F64 (float64 after framing, as psf)
@@ -74,6 +75,7 @@ SIGNATURES = {
     "kws_load_cnn_trad": (C.c_int, [_c_ctx, C.POINTER(C.c_float), C.c_size_t, C.c_int]),
     "kws_stream_vad_f32": (C.c_int, [_c_ctx, C.c_float, C.c_int, C.c_int, _i32p]),
     "kws_forward_cnn_trad_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, _f32p, _i32p]),
+    "kws_set_cnn_trad_math": (C.c_int, [_c_ctx, C.c_int]),
     "kws_infer_cnn_trad_i16": (C.c_int, [_c_ctx, _i16p, C.c_int, _f32p, _i32p]),
     "kws_softmax_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p]),
     "kws_stream_smooth_f32": (C.c_int, [_c_ctx, _f32p, C.c_int, C.c_int, _f32p, _i32p]),
@@ -234,6 +236,10 @@ class Context:
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         self._check(self._lib.kws_load_cnn_trad(self._h, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, int(num_classes)),
                     ModelError)
+
+    def set_cnn_trad_math(self, math: int):
+        """KWS_CT_F16_PAIR (0, default) or KWS_CT_BF16_TRIPLE (1): arithmetic of cnn-trad-fpool3's GEMM layers."""
+        self._check(self._lib.kws_set_cnn_trad_math(self._h, int(math)), ModelError)
 
     def forward_cnn_trad_f32(self, feat, logits, label=None):
         self._check(self._lib.kws_forward_cnn_trad_f32(self._h, _ptr(feat), int(feat.shape[0]), _ptr(logits),

@@ -1302,6 +1302,54 @@ def test_cnn_trad_fpool3_matches_its_cpu_definition(dev):
     assert clear.mean() > 0.8
 
 
+def test_cnn_trad_f16_pair_arithmetic_holds_over_range(dev):
+    """cnn-trad-fpool3's default arithmetic (f16 pairs, three MFMAs per k-block, KWS_CT_F16_PAIR) against a float64
+    evaluation of the model's CPU definition, over inputs and weights that stress f16's range: features scaled by 1e-3 .. 1e3,
+    an all-zero clip, a clip with one huge value, half-empty clips; convolution weights x 8 and x 0.05, large biases.  The
+    per-clip power-of-two scales come from rigorous bounds, so nothing may overflow: finite logits everywhere, error against
+    float64 within 4x of what torch's own f32 forward shows on the same clip (floor 2e-6 of the logit scale), and within
+    3e-6 of the scale of the exact three-way bf16 arithmetic (KWS_CT_BF16_TRIPLE) run on the same context."""
+    from kws import _native
+    from kws.libs.models import CnnTradFpool3
+    from oracle import cnn_trad as o_ct
+
+    torch.manual_seed(31)
+    x = torch.randn(24, 1, 99, 10) * 8.0
+    x[0] = 0.0
+    x[1] *= 1e-3
+    x[2] *= 1e3
+    x[3] *= 60.0
+    x[4, :, 50:] = 0.0
+    x[5] = torch.randn(1, 99, 10) * 0.01
+    x[5, 0, 40, 3] = 5000.0                      # one huge feature among tiny ones
+    x[6] = x[6].abs()
+    x[7] = -x[7].abs()
+    for seed, gain, bias_gain in ((11, 1.0, 1.0), (12, 8.0, 1.0), (13, 0.05, 1.0), (14, 1.0, 300.0)):
+        state = o_ct.random_state(seed=seed)
+        for k in state:
+            if k.startswith("conv") and k.endswith("weight"):
+                state[k] = state[k] * gain
+            if k.startswith("conv") and k.endswith("bias"):
+                state[k] = state[k] * bias_gain
+        m = CnnTradFpool3(12)
+        m.load_state_dict(state)
+        ref64 = o_ct.forward({k: v.double() for k, v in state.items()}, x.double())
+        ref32 = o_ct.forward(state, x)
+        ctx = m._context(0)
+        ctx.set_cnn_trad_math(_native.KWS_CT_F16_PAIR)
+        pair = m.forward(x.to(dev)).cpu().double()
+        ctx.set_cnn_trad_math(_native.KWS_CT_BF16_TRIPLE)
+        triple = m.forward(x.to(dev)).cpu().double()
+        ctx.set_cnn_trad_math(_native.KWS_CT_F16_PAIR)
+        assert torch.isfinite(pair).all() and torch.isfinite(triple).all(), (seed, gain)
+        for i in range(x.shape[0]):
+            scale = max(1.0, float(ref64[i].abs().max()))
+            e_pair = float((pair[i] - ref64[i]).abs().max())
+            e_f32 = float((ref32[i].double() - ref64[i]).abs().max())
+            assert e_pair <= max(4.0 * e_f32, 2e-6 * scale), (seed, gain, bias_gain, i, e_pair, e_f32, scale)
+            assert float((pair[i] - triple[i]).abs().max()) <= 3e-6 * scale, (seed, gain, i)
+
+
 def test_cnn_trad_fpool3_fused_wav_to_label(dev):
     """BASELINE configs[2] (MFCC + cnn-trad-fpool3 fused): int16 PCM through kws_infer_cnn_trad_i16 vs the oracle's
     MFCC followed by the model's CPU definition; the two-call path (kws_mfcc_i16, kws_forward_cnn_trad_f32) gives
