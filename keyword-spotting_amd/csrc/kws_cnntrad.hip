@@ -38,6 +38,7 @@ constexpr int PL_ZERO_OFF = (CT_P2 * PL_STRIDE + 255) / 256 * 256;      // 43 00
 constexpr int PL_ZERO_BYTES = 256 + 3 * 32 + 32;                        // natural offset mod 256, + channel block, + read width
 constexpr int PLANE_BYTES = PL_ZERO_OFF + PL_ZERO_BYTES;                // one bf16 piece plane [pos][64 cin + pad] + zero region
 constexpr int CT_LDS_BYTES = XP_BYTES + 3 * PLANE_BYTES;                // 138 368
+constexpr int WIN_PLANE_BYTES = XP_H * CT_F * 16;                       // 18 880: f16-pair arithmetic, conv1's input windows per piece
 constexpr int CT_NW = 8, CT_NT = CT_NW * 64;
 constexpr int C1_TILES = CT_T / 3;                                      // 33 tiles of 3 time rows x 10 bins (30 of 32 columns)
 constexpr int C2_TILES = (CT_P2 + 31) / 32;                             // 10
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
     float* xp = reinterpret_cast<float*>(smem);
     unsigned char* planes = smem + XP_BYTES;
     constexpr int NP = H2 ? 2 : 3;  // operand pieces
+    unsigned char* win = planes + NP * PLANE_BYTES;  // H2: conv1's pre-split input windows, [piece][padded row][start column][8 x f16]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, col = lane & 31;
     const int clip = blockIdx.x;
     if (clip >= B) return;
@@ -140,6 +142,18 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
             const int i = tid + n * CT_NT;
             if (i < CT_T * CT_F) xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = v[n] * s0;
         }
+        __syncthreads();
+        // conv1's B operands, split ONCE: window (padded row r, start column f) = the eight consecutive scaled inputs a lane
+        // needs for one kernel row, as one 16-byte hi and one 16-byte lo' fragment.  (Gathered and split per use it was
+        // 8 LDS reads + ~30 VALU instructions per three MFMAs, and conv1 took more than a third of the kernel.)
+        for (int i = tid; i < XP_H * CT_F; i += CT_NT) {
+            const float* src = xp + (i / CT_F) * XP_W + i % CT_F;
+            const float y[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+            uintx4 hi, lo;
+            split2(y, hi, lo);
+            *reinterpret_cast<uintx4*>(win + i * 16) = hi;
+            *reinterpret_cast<uintx4*>(win + i * 16 + WIN_PLANE_BYTES) = lo;
+        }
     } else {
         for (int i = tid; i < CT_T * CT_F; i += CT_NT)
             xp[(i / CT_F + 9) * XP_W + i % CT_F + 3] = feat[(size_t)clip * (CT_T * CT_F) + i];
@@ -163,32 +177,52 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
         }
         float bias[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = w.c1_b[ct * 32 + row_of(r, half)];
+        for (int r = 0; r < 16; ++r) bias[r] = w.c1_b[ct * 32 + row_of(r, half)] * s1;  // H2: in the planes' scale (s1 = 1 otherwise)
+        const float ps1 = post1 * s1;
         const int cc = col < 30 ? col : 29;
         const int tr = cc / CT_F, f = cc % CT_F;
         const bool owner = col < 30 && f % 3 == 0 && f < 9;
+#ifdef KWS_X_CT_NO_CONV1  // timing ablation: no conv1 (the planes keep whatever LDS held)
+        for (int u = C1_TILES; u < C1_TILES; u += CT_NW / 2) {
+#else
         for (int u = wv >> 1; u < C1_TILES; u += CT_NW / 2) {
+#endif
             const int t = 3 * u + tr;
             const float* base = xp + (t + half) * XP_W + f;
             floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc2 = acc;  // two chains, summed below
-            float y[2][8];
-            auto gather = [&](int kb, float (&dst)[8]) {
+            if constexpr (H2) {
+                // B operand = the pre-split window (padded row t + 2kb + half, start column f): two aligned ds_read_b128 per
+                // k-block, no VALU work; fetched two k-blocks ahead.  acc = hi * hi, acc2 = the cross terms (units of 2^-11)
+                const unsigned char* wb = win + ((t + half) * CT_F + f) * 16;
+                uintx4 bq[3][2];
+                auto wload = [&](int kb, uintx4 (&d)[2]) {
+                    d[0] = *reinterpret_cast<const uintx4*>(wb + kb * (2 * CT_F * 16));
+                    d[1] = *reinterpret_cast<const uintx4*>(wb + kb * (2 * CT_F * 16) + WIN_PLANE_BYTES);
+                };
+                wload(0, bq[0]);
+                wload(1, bq[1]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dst[j] = base[kb * 2 * XP_W + j];
-            };
-            gather(0, y[0]);
-            gather(1, y[1]);
+                for (int kb = 0; kb < CT_K1H / 2; ++kb) {
+                    if (kb + 2 < CT_K1H / 2) wload(kb + 2, bq[(kb + 2) % 3]);
+#ifdef KWS_X_CT_NO_C1_MFMA  // timing ablation: conv1's loads and epilogue without the matrix instructions
+                    acc[kb] += __builtin_bit_cast(float, bq[kb % 3][0][0] ^ bq[kb % 3][1][1] ^ af[kb][0][0] ^ af[kb][NP - 1][1]);
+#else
+                    acc2 = mfma_f16(af[kb][0], bq[kb % 3][1], acc2);
+                    acc = mfma_f16(af[kb][0], bq[kb % 3][0], acc);
+                    acc2 = mfma_f16(af[kb][NP - 1], bq[kb % 3][0], acc2);
+#endif
+                }
+            } else {
+                float y[2][8];
+                auto gather = [&](int kb, float (&dst)[8]) {
 #pragma unroll
-            for (int kb = 0; kb < CT_K1H / 2; ++kb) {
-                const int cur = kb & 1;
-                if constexpr (H2) {  // acc = hi * hi, acc2 = the cross terms (in units of 2^-11)
-                    uintx4 bh, bl;
-                    split2(y[cur], bh, bl);
-                    if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
-                    acc2 = mfma_f16(af[kb][0], bl, acc2);
-                    acc = mfma_f16(af[kb][0], bh, acc);
-                    acc2 = mfma_f16(af[kb][NP - 1], bh, acc2);
-                } else {
+                    for (int j = 0; j < 8; ++j) dst[j] = base[kb * 2 * XP_W + j];
+                };
+                gather(0, y[0]);
+                gather(1, y[1]);
+#pragma unroll
+                for (int kb = 0; kb < CT_K1H / 2; ++kb) {
+                    const int cur = kb & 1;
                     uintx4 bh, bm, bl;
                     split3(y[cur], bh, bm, bl);
                     if (kb + 2 < CT_K1H / 2) gather(kb + 2, y[cur]);
@@ -201,12 +235,36 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                     acc2 = mfma_bf16(af[kb][0], bh, acc2);
                 }
             }
-            if constexpr (H2)
-                acc = (acc + acc2 * LO_UNSCALE) * post1;
-            else
-                acc += acc2;
+            if constexpr (!H2) acc += acc2;
             // bias, ReLU, max over bins (f, f+1, f+2) via two lane shifts; lanes with f in {0,3,6} own a pooled value
             const int p = t * CT_FP + f / 3;
+#ifdef KWS_X_CT_NO_C1_EPILOGUE  // timing ablation: conv1 without its epilogue (one store keeps the accumulators alive)
+            if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.f) planes[p] = 1;
+            continue;
+#endif
+            if constexpr (H2) {
+                // relu(x * post + b) * s1 is monotone in x, so the pool runs on the raw sums (two DPP maxima per value) and the
+                // affine map, with s1 folded in (powers of two: exact), once on the maximum -- same bits as pooling afterwards
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float m[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float v = acc[r + e] + acc2[r + e] * LO_UNSCALE;
+                        const float a = fmaxf(v, lane_up(v));
+                        m[e] = relu(fmaxf(a, lane_up(a)) * ps1 + bias[r + e]);
+                    }
+                    if (owner) {  // channels co, co+1 (co even) as one dword per piece
+                        const int co = ct * 32 + row_of(r, half);
+                        uint32_t* dst = reinterpret_cast<uint32_t*>(planes + p * PL_STRIDE + co * 2);
+                        uint32_t hi, lo;
+                        split_pair(m[0], m[1], hi, lo);
+                        dst[0] = hi;
+                        dst[PLANE_BYTES / 4] = lo;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float m[2];
@@ -219,17 +277,10 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                 if (owner) {  // channels co, co+1 (co even) as one dword per piece
                     const int co = ct * 32 + row_of(r, half);
                     uint32_t* dst = reinterpret_cast<uint32_t*>(planes + p * PL_STRIDE + co * 2);
-                    if constexpr (H2) {
-                        uint32_t hi, lo;
-                        split_pair(m[0] * s1, m[1] * s1, hi, lo);
-                        dst[0] = hi;
-                        dst[PLANE_BYTES / 4] = lo;
-                    } else {
-                        const float r0 = m[0] - top16(m[0]), r1 = m[1] - top16(m[1]);
-                        dst[0] = pack_top16(m[0], m[1]);
-                        dst[PLANE_BYTES / 4] = pack_top16(r0, r1);
-                        dst[2 * PLANE_BYTES / 4] = pack_top16(r0 - top16(r0), r1 - top16(r1));
-                    }
+                    const float r0 = m[0] - top16(m[0]), r1 = m[1] - top16(m[1]);
+                    dst[0] = pack_top16(m[0], m[1]);
+                    dst[PLANE_BYTES / 4] = pack_top16(r0, r1);
+                    dst[(NP - 1) * PLANE_BYTES / 4] = pack_top16(r0 - top16(r0), r1 - top16(r1));
                 }
             }
         }
@@ -293,7 +344,11 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
 #pragma unroll
         for (int i = 0; i < NTILE; ++i) ba[i] = b_addr(0, i);
         b_load(ba, 0, bf[0]);
+#ifdef KWS_X_CT_NO_CONV2  // timing ablation: no conv2 loop
+        for (int kk = CT_K2H * CT_K2W; kk < CT_K2H * CT_K2W; ++kk) {
+#else
         for (int kk = 0; kk < CT_K2H * CT_K2W; ++kk) {
+#endif
             const unsigned char* ba_next[NTILE];
 #pragma unroll
             for (int i = 0; i < NTILE; ++i) ba_next[i] = b_addr(kk + 1 < CT_K2H * CT_K2W ? kk + 1 : kk, i);
@@ -319,7 +374,11 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                             acc[i][dst] = mfma_bf16(af[cb][pa], bf[cur][i][pb], acc[i][dst]);
                         __builtin_amdgcn_sched_barrier(0);
                         const int n = q * NTILE + i;  // one B load (tile n / NP, piece n % NP) of the next k-block per MFMA
+#ifdef KWS_X_CT_NO_BLOAD  // timing ablation: B operands are not refreshed
+                        if (n < 0) {
+#else
                         if (n < NP * NTILE) {
+#endif
                             const unsigned char* src = (cb < 3 ? ba[n / NP] + (cb + 1) * 32 : ba_next[n / NP]) + (n % NP) * PLANE_BYTES;
                             bf[cur ^ 1][n / NP][n % NP] = *reinterpret_cast<const uintx4*>(src);
                             __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +386,11 @@ __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights 
                     }
                     // last use of an A piece: three-way lo after product 0, mid after 3, hi after 5; pair hi after 1, lo' after 2
                     const int done = H2 ? (q == 1 ? 0 : (q == 2 ? 1 : -1)) : (q == 0 ? 2 : (q == 3 ? 1 : (q == 5 ? 0 : -1)));
+#ifdef KWS_X_CT_NO_ALOAD  // timing ablation: A operands are not refreshed
+                    if (false) {
+#else
                     if (more && done >= 0) {
+#endif
                         af[cb][done] = asrc[a_index(kk + 1, cb, done)];
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -476,7 +539,7 @@ __global__ __launch_bounds__(DN_WAVES * 64) void kws_cnntrad_dense_kernel(CnnTra
 
 }  // namespace
 
-constexpr int CT_LDS_BYTES_H2 = XP_BYTES + 2 * PLANE_BYTES;
+constexpr int CT_LDS_BYTES_H2 = XP_BYTES + 2 * PLANE_BYTES + 2 * WIN_PLANE_BYTES;  // 132 800
 
 hipError_t cnntrad_init_device() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kws_cnntrad_conv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
