@@ -56,7 +56,7 @@ __device__ __forceinline__ float lane_up(float v) { return from_lane_above(v); }
 // 2^-11 at the end (the dropped lo*lo term is <= 2^-22 of the product).  THREE v_mfma_f32_32x32x16_f16 per f32 k-block
 // instead of the six bf16 ones of the three-way split, two operand pieces to load instead of three -- this model is
 // bound by the matrix pipe, so that is the lever -- for logits that differ from float64 by what torch's own f32 forward
-// differs by (tools/cnntrad_f16_pair_sim.py).  Range: weights are scaled per layer at load time so that max |w| s < 2^15;
+// differs by (tests/test_cnntrad_f16_pair_sim.py).  Range: weights are scaled per layer at load time so that max |w| s < 2^15;
 // activations per CLIP, from rigorous bounds known before the values exist: M0 = max |feature| of the clip (measured
 // while staging), |conv1 out| <= max_c sum|w1[c]| M0 + max|b1|, |conv2 out| <= max_c sum|w2[c]| * that + max|b2|.  The
 // bounds are loose by 2^4..2^7 per layer; f16 keeps 11 bits down to 2^-14 and the scaled values top out below 2^15, so a
