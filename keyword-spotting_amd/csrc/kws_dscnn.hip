@@ -1218,8 +1218,13 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         // on their way over PCIe, in order), and the last one raises the host's flag behind them -- posted writes of one
         // device keep their order, so the host that sees the flag sees every stream's results.  No fence (they write whole
         // L2s back on this part).
+        // Only the workgroup that ran a stream's fc takes part (with time tiles it is the last of the stream's workgroups to
+        // arrive, so every tile of the stream is past its reads of the counter): one add per STREAM to this one address, not
+        // one per workgroup -- adds from eight XCDs to one address queue up at the coherence point.
+        int finishers = (int)gridDim.x;
+        if constexpr (CLUSTER) finishers /= cl_n;
         if (sp.h_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0 && atomicAdd(&sp.hops[1], 1) == (int)gridDim.x - 1) {
+        if (run_fc && tid == 0 && atomicAdd(&sp.hops[1], 1) == finishers - 1) {
             sp.hops[1] = 0;
             sp.hops[0] = hops_before + 1;
             if (sp.h_flag) __hip_atomic_store(sp.h_flag, hops_before + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

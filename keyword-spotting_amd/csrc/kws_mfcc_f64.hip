@@ -175,7 +175,15 @@ __global__ __launch_bounds__(REFINE_WAVES * 64) void kws_mfcc_refine_kernel(Fron
     // No fence anywhere here: on this part an agent-scope release writes the XCD's L2 back (the float32 kernel's 16 MB of
     // rows are still dirty in it) -- measured +12 us per launch.  Nothing inside this launch depends on another
     // workgroup's data; the counters are published to the next kernel by the kernel boundary.
-    if (tid == 0 && atomicAdd(&rl.ctr[6], 1) == (int)gridDim.x - 1) {
+    // Who resets the counters: the last of the workgroups that HAD work (all of them know n, hence how many they are), or
+    // workgroup 0 alone when the list is empty.  A workgroup without work does not touch the counter -- with every workgroup
+    // adding to one address across eight XCDs the empty launch took 15.6 us, most of it that queue of atomics.  A would-be
+    // participant that has not started yet has not added either, so the reset cannot overtake its read of n.
+    const int per_wg = n_waves;
+    int participants = (n + per_wg - 1) / per_wg;
+    participants = participants < 1 ? 1 : (participants > (int)gridDim.x ? (int)gridDim.x : participants);
+    if ((int)blockIdx.x >= participants) return;
+    if (tid == 0 && atomicAdd(&rl.ctr[6], 1) == participants - 1) {
         const int rows = rl.ctr[1];  // flagged frames, counted by the float32 kernel next to its list entries
         const unsigned long long total = ((unsigned long long)(unsigned)rl.ctr[3] << 32 | (unsigned)rl.ctr[2]) + (unsigned long long)rows;
         rl.ctr[2] = (int)(unsigned)total;
