@@ -160,6 +160,12 @@ _CALIB_SRC = r"""
 #include <hip/hip_runtime.h>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+extern "C" __global__ void calib_f16(const halfx8* a, const halfx8* b, float* o) {
+    floatx16 c = {};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[threadIdx.x], b[threadIdx.x], c, 0, 0, 0);
+    o[threadIdx.x] = c[0] + c[5] * 3.0f;
+}
 extern "C" __global__ void calib_bf16(const bf16x8* a, const bf16x8* b, float* o) {
     floatx16 c = {};
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[threadIdx.x], b[threadIdx.x], c, 0, 0, 0);
@@ -267,6 +273,14 @@ def lint_function(body, mfma_waits, default_mfma_wait):
                     sgpr_valu_age[r] = 0
             if op.startswith("v_cmpx"):
                 exec_age = 0
+        elif op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            # no fall-through: what follows in the text is reached only through a label, from code this linear walk has not
+            # just seen (the compiler schedules those joins; the hand-written asm blocks this lint is for are straight-line)
+            mfma_age.clear()
+            valu_age.clear()
+            dot_age.clear()
+            sgpr_valu_age.clear()
+            exec_age = None
         elif op.startswith(("ds_", "global_load", "buffer_load", "flat_load", "scratch_load")):
             for r in dst:  # a load's destination is rewritten later, behind s_waitcnt: the old producers no longer matter
                 mfma_age.pop(r, None)
