@@ -211,6 +211,7 @@ int kws_reserve(kws_ctx* ctx, int max_batch);
  * Changing it invalidates a captured streaming graph (re-captured on the next push). */
 #define KWS_PW_F32 1
 #define KWS_PW_SPLIT_BF16 4
+#define KWS_PW_PAIR_F16 5
 int kws_set_pointwise_math(kws_ctx* ctx, int math);
 
 /* Debug/parity aid: run the DS-CNN and also store every stored activation per clip to d_act

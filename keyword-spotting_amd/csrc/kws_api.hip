@@ -461,6 +461,16 @@ int kws_load_dscnn(kws_ctx* c, const float* blob, size_t n_floats, int num_class
     return kws_load_dscnn_ex(c, blob, n_floats, num_classes, 1);
 }
 
+static float pow2_weight_scale(const float* w, size_t n);
+static float max_row_abs_sum(const float* w, int rows, size_t row_len);
+// PLAIN f16-pair pieces of one weight already multiplied by its layer's scale: hi = f16(x), lo = f16(x - hi) (kws_split_mfma.h)
+static void pair_plain(float x, uint16_t& hb, uint16_t& lb) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    memcpy(&hb, &h, 2);
+    memcpy(&lb, &l, 2);
+}
+
 int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_classes, int input_channels) {
     KWS_GUARD_BEGIN
     if (!c) return KWS_EINVAL;
@@ -480,7 +490,8 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     const size_t o_c1w = 0, o_c1b = o_c1w + 6400, o_dw = o_c1b + 64, o_pww = o_dw + 4 * 64 * 12, o_pwb = o_pww + 4 * 4096,
                  o_fcw = o_pwb + 4 * 64, o_fcb = o_fcw + (size_t)num_classes * 64,
                  o_split = (o_fcb + num_classes + 3) & ~(size_t)3, o_c1s = o_split + 4 * 2 * 4 * 3 * 64 * 4,
-                 o_c1g = o_c1s + 2 * 7 * 3 * 64 * 4, o_raw = o_c1g + c1_floats, total = o_raw + n_floats;
+                 o_c1g = o_c1s + 2 * 7 * 3 * 64 * 4, o_raw = o_c1g + c1_floats,
+                 o_pwp = (o_raw + n_floats + 3) & ~(size_t)3, o_c1p = o_pwp + 4 * 2 * 4 * 2 * 64 * 4, total = o_c1p + 2 * 7 * 2 * 64 * 4;
     std::vector<float> h(total, 0.f);
     const float* src = blob;
     memcpy(&h[o_raw], blob, n_floats * sizeof(float));  // torch layouts, for the composed any-map path (kws_forward_map_f32)
@@ -514,6 +525,32 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                         }
                     }
     }
+    // the f16-pair images and the bounds behind the per-clip activation scales (kws_dscnn.hip, KWS_PW_PAIR_F16)
+    DscnnWeights& mw = c->mw;
+    if (input_channels == 1) {
+        const float sw = pow2_weight_scale(src, 6400);
+        int ke;
+        (void)std::frexp(sw, &ke);
+        mw.k_c1 = ke - 1;  // sw = 2^(ke - 1)
+        uint32_t* sp = reinterpret_cast<uint32_t*>(&h[o_c1p]);
+        for (int ct = 0; ct < 2; ++ct)
+            for (int kb = 0; kb < 7; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 32 * ct + (l & 31), f = 8 * kb + j;
+                        const float v = f < 50 ? src[co * 100 + (f / 10 + 5 * (l >> 5)) * 10 + f % 10] : 0.f;
+                        uint16_t hb, lb;
+                        pair_plain(v * sw, hb, lb);
+                        sp[(((size_t)(ct * 7 + kb) * 2 + 0) * 64 + l) * 4 + (j >> 1)] |= (uint32_t)hb << (16 * (j & 1));
+                        sp[(((size_t)(ct * 7 + kb) * 2 + 1) * 64 + l) * 4 + (j >> 1)] |= (uint32_t)lb << (16 * (j & 1));
+                    }
+        mw.c1_abs = max_row_abs_sum(src, 64, 100);
+        mw.c1_bmax = 0.f;
+        for (int i = 0; i < 64; ++i) mw.c1_bmax = std::max(mw.c1_bmax, std::fabs(src[6400 + i]));
+    } else {
+        mw.k_c1 = 0;
+        mw.c1_abs = mw.c1_bmax = 0.f;
+    }
     src += c1_floats;
     memcpy(&h[o_c1b], src, 64 * sizeof(float));
     src += 64;
@@ -546,6 +583,30 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                             dst |= (u >> 16) << (16 * (j & 1));
                         }
                     }
+        {
+            const float sw = pow2_weight_scale(pw_w, 4096);
+            int ke;
+            (void)std::frexp(sw, &ke);
+            mw.k_pw[b] = ke - 1;
+            uint32_t* pp = reinterpret_cast<uint32_t*>(&h[o_pwp]) + (size_t)b * (2 * 4 * 2 * 64 * 4);
+            for (int ct = 0; ct < 2; ++ct)
+                for (int m = 0; m < 4; ++m)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = 32 * ct + (l & 31), ci = 16 * m + 8 * (l >> 5) + j;
+                            uint16_t hb, lb;
+                            pair_plain(pw_w[co * 64 + ci] * sw, hb, lb);
+                            pp[(((size_t)(ct * 4 + m) * 2 + 0) * 64 + l) * 4 + (j >> 1)] |= (uint32_t)hb << (16 * (j & 1));
+                            pp[(((size_t)(ct * 4 + m) * 2 + 1) * 64 + l) * 4 + (j >> 1)] |= (uint32_t)lb << (16 * (j & 1));
+                        }
+            mw.dw_abs[b] = max_row_abs_sum(dw_w, 64, 9);
+            mw.pw_abs[b] = max_row_abs_sum(pw_w, 64, 64);
+            mw.dw_bmax[b] = mw.pw_bmax[b] = 0.f;
+            for (int i = 0; i < 64; ++i) {
+                mw.dw_bmax[b] = std::max(mw.dw_bmax[b], std::fabs(dw_b[i]));
+                mw.pw_bmax[b] = std::max(mw.pw_bmax[b], std::fabs(pw_b[i]));
+            }
+        }
         src += 576 + 64 + 4096 + 64;
     }
     memcpy(&h[o_fcw], src, (size_t)num_classes * 64 * sizeof(float));
@@ -572,6 +633,8 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->mw.pw_b = d + o_pwb;
     c->mw.pw_split = reinterpret_cast<const uint32_t*>(d + o_split);
     c->mw.c1_split = reinterpret_cast<const uint32_t*>(d + o_c1s);
+    c->mw.pw_pair = reinterpret_cast<const uint32_t*>(d + o_pwp);
+    c->mw.c1_pair = reinterpret_cast<const uint32_t*>(d + o_c1p);
     c->mw.fc_w = d + o_fcw;
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
@@ -704,8 +767,9 @@ static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits,
     if (c->mw.in_channels > 1) {
         // multi-channel input (models.py:125,135): conv1 in its own kernel through the context scratch, then the fused
         // kernel from block 1 on; the diagnostics variants exist for the single-channel model only
-        if (d_act || d_stamps || mode != KWS_PW_SPLIT_BF16)
-            return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": input_channels > 1 runs on the split-bf16 product kernel only");
+        if (d_act || d_stamps || (mode != KWS_PW_SPLIT_BF16 && mode != KWS_PW_PAIR_F16))
+            return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": input_channels > 1 runs on the product kernel only");
+        mode = KWS_PW_SPLIT_BF16;  // the pre-convolved entry computes on the bf16 triple
         rc = grow_conv_ws(c, (size_t)B * 64 * 141, fn);
         if (rc) return rc;
         HIP_TRY(c, launch_conv1_general(c->stream, d_feat, B, c->mw.in_channels, c->mw.c1_general, c->mw.c1_b, c->d_conv_ws));
@@ -783,8 +847,8 @@ int kws_forward_map_debug_f32(kws_ctx* c, const float* d_feat, int B, int T, int
 
 int kws_set_pointwise_math(kws_ctx* c, int math) {
     if (!c) return KWS_EINVAL;
-    if (math != KWS_PW_F32 && math != KWS_PW_SPLIT_BF16)
-        return fail(c, KWS_EINVAL, "kws_set_pointwise_math: math must be KWS_PW_F32 or KWS_PW_SPLIT_BF16");
+    if (math != KWS_PW_F32 && math != KWS_PW_SPLIT_BF16 && math != KWS_PW_PAIR_F16)
+        return fail(c, KWS_EINVAL, "kws_set_pointwise_math: math must be KWS_PW_F32, KWS_PW_SPLIT_BF16 or KWS_PW_PAIR_F16");
     if (math != c->pw_math && c->stream_graph) {  // the captured graph holds the other kernel
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         drop_stream_graph(c);
@@ -795,14 +859,14 @@ int kws_set_pointwise_math(kws_ctx* c, int math) {
 
 int kws_forward_debug_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, int32_t* d_label, float* d_act,
                           int use_mfma) {
-    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16)
-        return fail(c, KWS_EINVAL, "kws_forward_debug_f32: use_mfma must be 0, KWS_PW_F32 or KWS_PW_SPLIT_BF16");
+    if (c && use_mfma != 0 && use_mfma != KWS_PW_F32 && use_mfma != KWS_PW_SPLIT_BF16 && use_mfma != KWS_PW_PAIR_F16)
+        return fail(c, KWS_EINVAL, "kws_forward_debug_f32: use_mfma must be 0, KWS_PW_F32, KWS_PW_SPLIT_BF16 or KWS_PW_PAIR_F16");
     return forward_impl(c, d_feat, B, d_logits, d_label, d_act, use_mfma, "kws_forward_debug_f32");
 }
 
 int kws_forward_stamps_f32(kws_ctx* c, const float* d_feat, int B, float* d_logits, uint64_t* d_stamps, int mode) {
     if (!d_stamps) return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: d_stamps is NULL");
-    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 6)
+    if (mode != 0 && mode != 1 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6)
         return fail(c, KWS_EINVAL, "kws_forward_stamps_f32: unknown kernel variant");
     return forward_impl(c, d_feat, B, d_logits, nullptr, nullptr, mode, "kws_forward_stamps_f32",
                         reinterpret_cast<unsigned long long*>(d_stamps));
@@ -1332,7 +1396,7 @@ int kws_stream_close(kws_ctx* c) {
 // frame kernel followed -- if logits are wanted -- by the DS-CNN kernel over the advanced ring.
 static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32_t* d_label, bool timed) {
     hipError_t e;
-    if (d_logits && c->pw_math == KWS_PW_SPLIT_BF16) {
+    if (d_logits && (c->pw_math == KWS_PW_SPLIT_BF16 || c->pw_math == KWS_PW_PAIR_F16)) {
         const bool was = c->prof;
         c->prof = was && timed;
         ProfScope ps(c, KWS_K_DSCNN);
@@ -1343,7 +1407,7 @@ static hipError_t stream_enqueue(kws_ctx* c, const int16_t* d_hop, float* d_logi
         const StreamPush sp = {c->fp, c->ft, d_hop, c->d_pcm_ring, c->ring_len, c->d_hops, c->d_refine, 0, cluster, c->d_cl_part, c->d_cl_count,
                                host ? c->h_stream_logits : nullptr, host ? c->h_stream_label : nullptr, host ? c->h_stream_flag : nullptr};
         c->last_push_host = host;
-        return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label);
+        return launch_dscnn_stream(c->stream, c->mw, sp, c->d_feat_ring, c->n_streams, d_logits, d_label, c->pw_math == KWS_PW_PAIR_F16);
     }
     c->last_push_host = false;
     {
@@ -1381,7 +1445,7 @@ int kws_stream_push_i16(kws_ctx* c, const int16_t* d_hop, float* d_logits, int32
     // takes 6.9 us of host time against 3.0 us for the plain launch, and completion is observed 8 us later in all
     // (tools/graph_overhead.hip: 20.6 vs 12.3 us launch -> hipStreamSynchronize for a trivial kernel; still 23.6 vs 20.3 us at
     // four kernels).  use_graph is honoured for the multi-launch routes only, where it saves host time per push.
-    if (use_graph && d_logits && c->pw_math == KWS_PW_SPLIT_BF16) use_graph = 0;
+    if (use_graph && d_logits && (c->pw_math == KWS_PW_SPLIT_BF16 || c->pw_math == KWS_PW_PAIR_F16)) use_graph = 0;
     if (use_graph) {
         // one hipGraph per (hop, logits, label) pointer triple: the two launches replay as one submission
         if (!c->stream_graph || c->graph_key[0] != d_hop || c->graph_key[1] != d_logits || c->graph_key[2] != d_label) {

@@ -62,11 +62,6 @@ __device__ __forceinline__ float lane_up(float v) { return from_lane_above(v); }
 // bounds are loose by 2^4..2^7 per layer; f16 keeps 11 bits down to 2^-14 and the scaled values top out below 2^15, so a
 // value keeps full relative precision down to 2^-29 of its layer's bound and an absolute 2^-40 of it below that: no
 // overflow for any input, no precision cliff.  All scalings are by powers of two (exact).
-typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ floatx16 mfma_f16(const uintx4& a, const uintx4& b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
-}
 __device__ __forceinline__ void split_pair(float even, float odd, uint32_t& hi, uint32_t& lo) {
     const halfx2 h = {(_Float16)even, (_Float16)odd};
     const halfx2 l = {(_Float16)((even - (float)h[0]) * 2048.f), (_Float16)((odd - (float)h[1]) * 2048.f)};
@@ -83,14 +78,6 @@ __device__ __forceinline__ void split2(const float (&y)[8], uintx4& hi, uintx4& 
     }
 }
 constexpr float LO_UNSCALE = 1.f / 2048.f;
-// the power of two s with bound * s < 2^15 (bound >= 0; exponent kept within +-100 so that 1/s is a normal float too)
-__device__ __forceinline__ int pow2_exp_for(float bound) {
-    const int e = (int)((__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu);  // bound < 2^(e - 126)
-    const int k = 141 - e;
-    return k < -100 ? -100 : (k > 100 ? 100 : k);
-}
-__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23); }
-
 template <bool H2>
 __global__ __launch_bounds__(CT_NT) void kws_cnntrad_conv_kernel(CnnTradWeights w, const float* __restrict__ feat, int B,
                                                                  float* __restrict__ conv_out, float* __restrict__ clip_scale) {

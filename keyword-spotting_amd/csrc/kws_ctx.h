@@ -39,7 +39,7 @@ struct kws_ctx {
     float* d_model = nullptr;
     DscnnWeights mw{};
     bool model_ready = false;
-    int pw_math = KWS_PW_SPLIT_BF16;  // kernel variant of the product entry points
+    int pw_math = KWS_PW_PAIR_F16;    // kernel variant of the product entry points
     // cnn-trad-fpool3
     void* d_cnntrad = nullptr;
     CnnTradWeights tw{};

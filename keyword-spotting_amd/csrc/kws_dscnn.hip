@@ -42,6 +42,8 @@
 //   Z1 (block1 out, 47x3)  @ 0      .. 9152      Z0 (conv1 out, 47x3)  @ 9152  .. 18304
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
 //   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled
+#include <type_traits>
+
 #include "kws_internal.h"
 #include "kws_mfcc_dev.h"
 #include "kws_split_mfma.h"
@@ -67,8 +69,11 @@ constexpr int OFF_DWTAB = 38784;                 // [2][64][12]  double-buffered
 constexpr int OFF_PWB = OFF_DWTAB + 2 * 768;     // [2][64]      pointwise bias, double-buffered
 constexpr int OFF_POOLED = OFF_PWB + 2 * 64;     // [64]
 constexpr int OFF_POOLBUF = OFF_DWTAB;           // [NW][64] aliases depthwise buffer 0 (idle during block 4)
+constexpr int OFF_WMAX = OFF_POOLED + 64 + 8;    // [4][NW] f16-pair arithmetic: per-wavefront maxima of a stage's stored output.  Sets: features 0,
+                                                 // conv1 1, block 1 2 (+ its leftover combine 3), block 2 0 (+ combine 1): a set is
+                                                 // rewritten two barriers after its last reader at the earliest
 constexpr int LDS_FLOATS = 40960;                // 160 KiB
-static_assert(OFF_POOLED + 64 <= LDS_FLOATS, "LDS overflow");
+static_assert(OFF_WMAX + 4 * NW <= LDS_FLOATS, "LDS overflow");
 static_assert(NW * 64 <= 768, "pool scratch must fit one depthwise buffer");
 static_assert(OFF_FEAT + FEAT_H * FEAT_W <= OFF_Z2, "feature pad overlaps Z2");
 static_assert(CH * 12 <= 2 * NT, "table staging assumes at most two elements per thread");
@@ -168,11 +173,47 @@ __device__ __forceinline__ void fetch_block_tables(const DscnnWeights& w, int n,
     r.d1 = NT + tid < CH * 12 ? src[NT + tid] : 0.f;
     r.b = tid < CH ? w.pw_b[(n - 1) * CH + tid] : 0.f;
 }
-__device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r) {
+// s_dwb / s_pwb (f16-pair arithmetic; 1 otherwise): the block's activations are kept in LDS scaled by per-clip powers of two,
+// so its depthwise bias is stored in the units of its input and its pointwise bias (= accumulator seed and ring value) in the
+// units of its output.
+__device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r, float s_dwb = 1.f, float s_pwb = 1.f) {
     float* dwtab = lds + OFF_DWTAB + ((n - 1) & 1) * 768;
-    if (tid < CH * 12) dwtab[tid] = r.d0;
-    if (NT + tid < CH * 12) dwtab[NT + tid] = r.d1;
-    if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b;
+    if (tid < CH * 12) dwtab[tid] = tid % 12 == 9 ? r.d0 * s_dwb : r.d0;
+    if (NT + tid < CH * 12) dwtab[NT + tid] = (NT + tid) % 12 == 9 ? r.d1 * s_dwb : r.d1;
+    if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b * s_pwb;
+}
+// f16-pair arithmetic: what a stage needs to know about the clip's scales (all powers of two)
+struct PairCtx {
+    float e = 1.f;          // the stage's operand scale: depthwise output (in the units its input is stored in) * e < 2^15
+    float s_dwb = 1.f;      // next block's depthwise bias factor = this block's output units
+    float s_pwb = 1.f;      // next block's pointwise bias factor = the next block's output units
+    float inv_out = 1.f;    // block 4: pooled sums back to true units
+};
+// wavefront maximum of non-negative values -> per-wavefront slot (read by everyone after the stage's barrier).  DPP row
+// scans, no LDS round trips: six dependent ds_bpermute exchanges sat at the end of every wavefront's stage, in front of the barrier.
+__device__ __forceinline__ void publish_wave_max(float* lds, int set, int wv, int lane, float mx) {
+    auto step = [](float m, auto ctrl, auto row_mask) {
+        return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), decltype(ctrl)::value,
+                                                                              decltype(row_mask)::value, 0xf, false)));
+    };
+    mx = step(mx, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+    mx = step(mx, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+    mx = step(mx, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+    mx = step(mx, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+    mx = step(mx, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1, 3
+    mx = step(mx, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2, 3
+    if (lane == 63) lds[OFF_WMAX + set * NW + wv] = mx;
+}
+// the maximum over n_sets consecutive sets (NW values each): two 16-byte reads per set
+__device__ __forceinline__ float read_stage_max(const float* lds, int set0, int n_sets) {
+    static_assert(NW == 8 && OFF_WMAX % 4 == 0, "the stage maxima are read as float4 pairs");
+    float m = 0.f;
+    const float4* q = reinterpret_cast<const float4*>(lds + OFF_WMAX + set0 * NW);
+    for (int i = 0; i < 2 * n_sets; ++i) {
+        const float4 v = q[i];
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    return m;
 }
 
 // Pointwise weights of the running block as MFMA A operands.
@@ -183,34 +224,35 @@ __device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, c
 //     j = 0..7 -- eight bf16 per lane and (ct, m, p), pre-split on the host (exactly: hi + mid + lo == W).  Only
 //     two k-blocks m are in registers at a time: ring[m & 1] is fetched one k-block ahead from global memory
 //     (L1/L2-resident; the same bytes per block as the f32 path loads), which frees 48 registers.
-typedef uintx4 AFrag[2][3];  // [channel tile][piece] of one k-block
-template <bool SPLIT>
-struct PwRegs {
+// NP pieces per operand: 3 = bf16 hi/mid/lo (modes 4, 6), 2 = f16 pair (mode 5)
+template <int NP>
+struct PwRing {
+    uintx4 ring[2][2][NP];  // [ring slot][channel tile][piece] of one k-block
+};
+struct PwRegsF32 {
     float wa[2][32];
 };
-template <>
-struct PwRegs<true> {
-    AFrag ring[2];
-};
 template <int MODE>
-using PwOperands = PwRegs<(MODE >= 4)>;
-__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) {
+using PwOperands = std::conditional_t<(MODE >= 4), PwRing<(MODE == 5 ? 2 : 3)>, PwRegsF32>;
+__device__ __forceinline__ void load_pointwise(const DscnnWeights& w, int n, int lane, PwRegsF32& o) {
     const float* pw = w.pw_w + (n - 1) * CH * CH + 8 * (lane >> 5) * CH + (lane & 31);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int s = 0; s < 32; ++s) o.wa[ct][s] = pw[(16 * (s >> 3) + (s & 7)) * CH + ct * 32];
 }
-__device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, AFrag& f) {
-    const uintx4* src = reinterpret_cast<const uintx4*>(w.pw_split) + (size_t)(n - 1) * (2 * 4 * 3 * 64) + lane;
+template <int NP>
+__device__ __forceinline__ void load_afrag(const DscnnWeights& w, int n, int m, int lane, uintx4 (&f)[2][NP]) {
+    const uintx4* src = reinterpret_cast<const uintx4*>(NP == 2 ? w.pw_pair : w.pw_split) + (size_t)(n - 1) * (2 * 4 * NP * 64) + lane;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) f[ct][p] = src[((ct * 4 + m) * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) f[ct][p] = src[((ct * 4 + m) * NP + p) * 64];
 }
 // first operands of block n: the whole block (f32) or its k-block 0 (split)
-__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<false>& o) { load_pointwise(w, n, lane, o); }
-__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegs<true>& o) { load_afrag(w, n, 0, lane, o.ring[0]); }
+__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRegsF32& o) { load_pointwise(w, n, lane, o); }
+template <int NP>
+__device__ __forceinline__ void load_block_head(const DscnnWeights& w, int n, int lane, PwRing<NP>& o) { load_afrag(w, n, 0, lane, o.ring[0]); }
 
 // ------------------------------------------------------------------------------------------------
 // conv1: D[cout][pos] = sum_k W[cout][k] * im2col[k][pos], k = kh*10 + kw, as 50 MFMA k-steps.
@@ -270,9 +312,14 @@ __device__ __forceinline__ void conv1_phase(const DscnnWeights& w, float* lds, i
 // one channel tile each, 6 and 7 have no conv1 work: one round, and the busiest SIMD (a dual and a single unit)
 // carries the matrix work of three single units but two split streams instead of three.
 // p_lo / p_hi: the positions this workgroup computes (the whole map, or the rows of one time tile: see PosRange).
-template <bool DUAL>
+// NP = 3: bf16 hi/mid/lo, six products per k-block.  NP = 2: f16 pairs, three (kws_split_mfma.h); the features are multiplied
+// by the clip's scale sx inside the split, the accumulators are in units sig0 = sx * (the layer's weight scale), the bias is
+// added in those units and the output is STORED in them (block 1's depthwise bias is scaled to match); mx collects the
+// largest stored value of this wavefront.
+template <bool DUAL, int NP>
 __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const float* featp, float* z0, int ptile, int ct, int lane,
-                                                 const uintx4 (&c1f)[7][3], int p_lo = 0, int p_hi = P0) {
+                                                 const uintx4 (&c1f)[7][NP], int p_lo, int p_hi, float sx, float sig0, float& mx) {
+    constexpr bool PAIR = NP == 2;
     const int half = lane >> 5, col = lane & 31;
     const int pos = p_lo + ptile * 32 + col;
     const int posc = pos < p_hi ? pos : p_hi - 1;
@@ -281,11 +328,11 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
     const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     floatx16 acc = zero, acc2 = zero;  // two chains per channel tile keep the matrix pipe fed
     floatx16 occ = zero, occ2 = zero;  // the other channel tile (DUAL)
-    const uintx4* osrc = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(ct ^ 1) * (7 * 3 * 64) + lane;
-    uintx4 of[2][3];                   // its A fragments: k-block kb in of[kb & 1], requested two k-blocks ahead
+    const uintx4* osrc = reinterpret_cast<const uintx4*>(PAIR ? w.c1_pair : w.c1_split) + (size_t)(ct ^ 1) * (7 * NP * 64) + lane;
+    uintx4 of[2][NP];                  // its A fragments: k-block kb in of[kb & 1], requested two k-blocks ahead
     auto load_other = [&](int kb) {
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) of[kb & 1][pc] = osrc[(kb * 3 + pc) * 64];
+        for (int pc = 0; pc < NP; ++pc) of[kb & 1][pc] = osrc[(kb * NP + pc) * 64];
     };
     if (DUAL) {
         load_other(0);
@@ -300,48 +347,86 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
             dst[j + 1] = v.y;
         }
     };
-    uintx4 bf[2][3];  // [buffer][hi, mid, lo] B operands: k-block kb multiplies while kb+1 is being split
+    uintx4 bf[2][NP];  // [buffer][piece] B operands: k-block kb multiplies while kb+1 is being split
     gather(0, y[0]);
     gather(1, y[1]);
-    split3(y[0], bf[0][0], bf[0][1], bf[0][2]);
+    if constexpr (PAIR)
+        split_pair8(y[0], sx, bf[0][0], bf[0][1]);
+    else
+        split3(y[0], bf[0][0], bf[0][1], bf[0][NP - 1]);
     gather(2, y[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 7; ++kb) {
         const int cur = kb & 1, nxt = cur ^ 1;
-        // the six products of this k-block (per channel tile), smallest first, spread over the next k-block's split
+        // the piece products of this k-block (per channel tile), smallest first, spread over the next k-block's split
         auto product = [&](int q) {
-            const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-            const int pb = (q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1);
+            // triple: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); pair: (hi,lo) (lo,hi) (hi,hi)
+            const int pa = PAIR ? (q == 1 ? 1 : 0) : (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0);
+            const int pb = PAIR ? (q == 0 ? 1 : 0) : ((q == 0 || q == 3 || q == 5) ? 0 : (q == 1 ? 2 : 1));
+            auto mm = [&](const uintx4& a, const uintx4& b, floatx16 c) {
+                if constexpr (PAIR)
+                    return mfma_f16(a, b, c);
+                else
+                    return mfma_bf16(a, b, c);
+            };
             if (q & 1)
-                acc2 = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc2);
+                acc2 = mm(c1f[kb][pa], bf[cur][pb], acc2);
             else
-                acc = mfma_bf16(c1f[kb][pa], bf[cur][pb], acc);
+                acc = mm(c1f[kb][pa], bf[cur][pb], acc);
             __builtin_amdgcn_sched_barrier(0);
             if (DUAL) {
                 if (q & 1)
-                    occ2 = mfma_bf16(of[cur][pa], bf[cur][pb], occ2);
+                    occ2 = mm(of[cur][pa], bf[cur][pb], occ2);
                 else
-                    occ = mfma_bf16(of[cur][pa], bf[cur][pb], occ);
+                    occ = mm(of[cur][pa], bf[cur][pb], occ);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            product(i);
+        if constexpr (PAIR) {
+            product(0);
             if (kb + 1 < 7) {
-                const float a0 = y[nxt][2 * i], a1 = y[nxt][2 * i + 1];
-                const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
-                bf[nxt][0][i] = pack_top16(a0, a1);
-                bf[nxt][1][i] = pack_top16(r0, r1);
-                bf[nxt][2][i] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    uint32_t h, l;
+                    split_pair2(y[nxt][2 * i], y[nxt][2 * i + 1], sx, h, l);
+                    bf[nxt][0][i] = h;
+                    bf[nxt][1][i] = l;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            product(1);
+            if (kb + 1 < 7) {
+#pragma unroll
+                for (int i = 2; i < 4; ++i) {
+                    uint32_t h, l;
+                    split_pair2(y[nxt][2 * i], y[nxt][2 * i + 1], sx, h, l);
+                    bf[nxt][0][i] = h;
+                    bf[nxt][1][i] = l;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb + 3 < 7) gather(kb + 3, y[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            product(2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                product(i);
+                if (kb + 1 < 7) {
+                    const float a0 = y[nxt][2 * i], a1 = y[nxt][2 * i + 1];
+                    const float r0 = a0 - top16(a0), r1 = a1 - top16(a1);
+                    bf[nxt][0][i] = pack_top16(a0, a1);
+                    bf[nxt][1][i] = pack_top16(r0, r1);
+                    bf[nxt][NP - 1][i] = pack_top16(r0 - top16(r0), r1 - top16(r1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            product(4);
+            if (kb + 3 < 7) gather(kb + 3, y[nxt]);
+            __builtin_amdgcn_sched_barrier(0);
+            product(5);
         }
-        product(4);
-        if (kb + 3 < 7) gather(kb + 3, y[nxt]);
-        __builtin_amdgcn_sched_barrier(0);
-        product(5);
         if (DUAL && kb + 2 < 7) {
             load_other(kb + 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -353,12 +438,14 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
             const int co = ct * 32 + row_of(r, half);
-            *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) =
-                make_float2(relu(acc[r] + w.c1_b[co]), relu(acc[r + 1] + w.c1_b[co + 1]));
+            const float v0 = relu(fmaf(w.c1_b[co], sig0, acc[r])), v1 = relu(fmaf(w.c1_b[co + 1], sig0, acc[r + 1]));
+            *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) = make_float2(v0, v1);
+            if constexpr (PAIR) mx = fmaxf(mx, fmaxf(v0, v1));
             if (DUAL) {
                 const int oo = (ct ^ 1) * 32 + row_of(r, half);
-                *reinterpret_cast<float2*>(z0 + pidx(oo, pos, P0 + 2)) =
-                    make_float2(relu(occ[r] + w.c1_b[oo]), relu(occ[r + 1] + w.c1_b[oo + 1]));
+                const float u0 = relu(fmaf(w.c1_b[oo], sig0, occ[r])), u1 = relu(fmaf(w.c1_b[oo + 1], sig0, occ[r + 1]));
+                *reinterpret_cast<float2*>(z0 + pidx(oo, pos, P0 + 2)) = make_float2(u0, u1);
+                if constexpr (PAIR) mx = fmaxf(mx, fmaxf(u0, u1));
             }
         }
     }
@@ -370,22 +457,24 @@ struct PosRange {
     int lo, hi;
 };
 
-template <bool RANGED = false>
-__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][3],
-                                                  PosRange rg = PosRange{0, P0}) {
+template <bool RANGED, int NP>
+__device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* lds, int tid, const uintx4 (&c1f)[7][NP],
+                                                  PosRange rg, float sx = 1.f, float sig0 = 1.f) {
     static_assert(P0 > 4 * 32 && P0 <= 5 * 32 && NW >= 6, "conv1 work split: four dual tiles + one tile in two halves");
     const float* featp = lds + OFF_FEAT;
     float* z0 = lds + OFF_Z0;
     const int lane = tid & 63, wv = tid >> 6;
+    float mx = 0.f;
     if constexpr (RANGED) {
         // a time tile holds at most 4 position tiles of 32: one (tile, channel tile) unit per wavefront, one round -- the
         // shortest critical path (a dual unit carries twice the matrix work); c1f holds channel tile wv & 1
         const int n_pt = (rg.hi - rg.lo + 31) / 32;
-        for (int u = wv; u < 2 * n_pt; u += NW) conv1_unit_split<false>(w, featp, z0, u >> 1, u & 1, lane, c1f, rg.lo, rg.hi);
+        for (int u = wv; u < 2 * n_pt; u += NW) conv1_unit_split<false, NP>(w, featp, z0, u >> 1, u & 1, lane, c1f, rg.lo, rg.hi, sx, sig0, mx);
     } else if (wv < 4)
-        conv1_unit_split<true>(w, featp, z0, wv, wv & 1, lane, c1f);
+        conv1_unit_split<true, NP>(w, featp, z0, wv, wv & 1, lane, c1f, 0, P0, sx, sig0, mx);
     else if (wv < 6)
-        conv1_unit_split<false>(w, featp, z0, 4, wv & 1, lane, c1f);
+        conv1_unit_split<false, NP>(w, featp, z0, 4, wv & 1, lane, c1f, 0, P0, sx, sig0, mx);
+    if constexpr (NP == 2) publish_wave_max(lds, 1, wv, lane, mx);
     if (tid < CH) {  // extra slots of the conv1 planes: no ring in block 1, slot P+1 is the zero pad
         z0[pidx(tid, P0, P0 + 2)] = 0.f;
         z0[pidx(tid, P0 + 1, P0 + 2)] = 0.f;
@@ -396,8 +485,8 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 // A quarter of the leftover tile of block N (see Leftover): k-block M (input channels 16M .. 16M+15) of tile Leftover<N>::TILE
 // for both output-channel tiles.  Eight stencil steps, one split, twelve MFMAs, the raw partial sums (no bias, no ReLU) of the
 // tile's valid columns to part[M][cout][position in tile].  af: the pre-split weights of k-block M (requested long before).
-template <int N>
-__device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int M, const AFrag& af) {
+template <int N, int NP>
+__device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int M, const uintx4 (&af)[2][NP], float e) {
     using G = Blk<N>;
     using L = Leftover<N>;
     const int half = lane >> 5, col = lane & 31;
@@ -433,15 +522,27 @@ __device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int 
                                          e ? dn.y : dn.x, mask_l, mask_r);
         }
     }
-    uintx4 bh, bm, bl;
-    split3(y, bh, bm, bl);
     floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+    if constexpr (NP == 2) {  // f16 pair: (hi,lo) (lo,hi) (hi,hi)
+        uintx4 bh, bl;
+        split_pair8(y, e, bh, bl);
+        asm volatile("s_nop 1" : "+v"(bh), "+v"(bl));  // the split is an asm block: keep the matrix core off its last write
+        acc0 = mfma_f16(af[0][0], bl, acc0);
+        acc1 = mfma_f16(af[1][0], bl, acc1);
+        acc0 = mfma_f16(af[0][1], bh, acc0);
+        acc1 = mfma_f16(af[1][1], bh, acc1);
+        acc0 = mfma_f16(af[0][0], bh, acc0);
+        acc1 = mfma_f16(af[1][0], bh, acc1);
+    } else {
+        uintx4 bh, bm, bl;
+        split3(y, bh, bm, bl);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {  // the six piece products, smallest first
-        const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-        const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
-        acc0 = mfma_bf16(af[0][pa], b, acc0);
-        acc1 = mfma_bf16(af[1][pa], b, acc1);
+        for (int q = 0; q < 6; ++q) {  // the six piece products, smallest first
+            const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
+            const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
+            acc0 = mfma_bf16(af[0][pa], b, acc0);
+            acc1 = mfma_bf16(af[1][pa], b, acc1);
+        }
     }
     float* part = lds + L::OFF_PART + M * (CH * L::NP);
     if (valid) {  // (plain stores of the accumulators: the compiler waits out the matrix-core write itself)
@@ -454,18 +555,22 @@ __device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int 
 }
 
 // After the block's barrier: the leftover tile's output = relu(bias + the four k-block partials, added in a fixed order).
-template <int N>
+template <int N, bool PAIR = false>
 __device__ __forceinline__ void leftover_combine(float* lds, int tid) {
     using G = Blk<N>;
     using L = Leftover<N>;
     const float* part = lds + L::OFF_PART;
     const float* pwb = lds + OFF_PWB + G::BUF * 64;
     float* zout = lds + G::OFF_OUT;
+    float mx = 0.f;
     for (int i = tid; i < CH * L::NP; i += NT) {
         const int co = i / L::NP, j = i - co * L::NP;
         const float s = (part[i] + part[CH * L::NP + i]) + (part[2 * CH * L::NP + i] + part[3 * CH * L::NP + i]);
-        zout[pidx(co, L::P0T + j, G::SOUT)] = relu(s + pwb[co]);
+        const float v = relu(s + pwb[co]);
+        zout[pidx(co, L::P0T + j, G::SOUT)] = v;
+        mx = fmaxf(mx, v);
     }
+    if constexpr (PAIR) publish_wave_max(lds, N == 1 ? 3 : 1, tid >> 6, tid & 63, mx);  // (pwb is stored in the accumulators' units)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,10 +585,13 @@ __device__ __forceinline__ void leftover_combine(float* lds, int tid) {
 // RANGED: only the positions rg.lo .. rg.hi - 1 (whole rows) are computed -- one time tile of a workgroup cluster.
 template <int N, int MODE, bool RANGED = false>
 __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, int tid, PwOperands<MODE>& pwo,
-                                            float* __restrict__ act4 = nullptr, PosRange rg = PosRange{0, 0}) {
+                                            float* __restrict__ act4 = nullptr, PosRange rg = PosRange{0, 0}, PairCtx pc = PairCtx{}) {
     using G = Blk<N>;
-    // the leftover tile of blocks 1 / 2 is K-split over four wavefronts (product path on whole maps only)
-    constexpr bool KSL = Leftover<N>::HAS && MODE == 4 && !RANGED;
+    constexpr bool PAIR = MODE == 5;          // f16 pairs: three products per k-block, activations in per-clip scaled units
+    constexpr int NP = PAIR ? 2 : 3;
+    constexpr int NPROD = PAIR ? 3 : 6;
+    // the leftover tile of blocks 1 / 2 is K-split over four wavefronts (product paths on whole maps only)
+    constexpr bool KSL = Leftover<N>::HAS && (MODE == 4 || MODE == 5) && !RANGED;
     const int p_lo = RANGED ? rg.lo : 0, p_hi = RANGED ? rg.hi : G::POUT;
 #ifdef KWS_X_DSCNN_SKIP_LEFTOVER  // timing experiment (wrong results): block 2 without its ninth tile, the upper bound of what
                                   // spreading that tile over idle wavefronts could win
@@ -524,6 +632,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) psum[ct][r] = 0.f;
+    float stage_max = 0.f;  // PAIR, blocks 1 and 2: this wavefront's largest stored output
 
     for (int t = wv; t < n_tiles; t += NW) {
         // column j of the tile is output position p_lo + t*TW - 1 + j: columns 0 and 31 are halo.  A halo column past the
@@ -614,13 +723,21 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 // and the wavefront sits behind the busy matrix pipe).  Smallest products first.
                 float y[8];
                 uintx4 bh, bm, bl;
-                auto product = [&](int ct, int m, int q) {  // q-th of the six piece products of k-block m, channel tile ct
-                    const int pa = q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0;
-                    const uintx4& b = (q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm);
-                    if (ct == 0)
-                        acc0 = mfma_bf16(pwo.ring[m & 1][0][pa], b, acc0);
-                    else
-                        acc1 = mfma_bf16(pwo.ring[m & 1][1][pa], b, acc1);
+                auto product = [&](int ct, int m, int q) {  // q-th of the piece products of k-block m, channel tile ct
+                    // triple: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); pair: (hi,lo) (lo,hi) (hi,hi)
+                    const int pa = PAIR ? (q == 1 ? 1 : 0) : (q == 0 ? 2 : (q == 2 || q == 3) ? 1 : 0);
+                    const uintx4& b = PAIR ? (q == 0 ? bl : bh) : ((q == 0 || q == 3 || q == 5) ? bh : (q == 1 ? bl : bm));
+                    if constexpr (PAIR) {
+                        if (ct == 0)
+                            acc0 = mfma_f16(pwo.ring[m & 1][0][pa], b, acc0);
+                        else
+                            acc1 = mfma_f16(pwo.ring[m & 1][1][pa], b, acc1);
+                    } else {
+                        if (ct == 0)
+                            acc0 = mfma_bf16(pwo.ring[m & 1][0][pa], b, acc0);
+                        else
+                            acc1 = mfma_bf16(pwo.ring[m & 1][1][pa], b, acc1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 };
 #pragma unroll
@@ -628,7 +745,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     const int m = s >> 3, j = s & 7;
                     Taps& tp = (s & 1) ? ta1 : ta0;
                     TapPair& tq = (s & 2) ? tq1 : tq0;  // step pair s >> 1
-                    const bool feed = m > 0 && j < 6;
+                    const bool feed = m > 0 && j < NPROD;
                     if (feed) product(0, m - 1, j);
                     take(tp, tq, s & 1);
                     y[j] = NO_STENCIL ? tp.mid : dw_eval(tp);
@@ -653,12 +770,17 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (j == 7) {
-                        split3(y, bh, bm, bl);
+                        if constexpr (PAIR) {
+                            split_pair8(y, pc.e, bh, bl);
+                            asm volatile("s_nop 1" : "+v"(bh), "+v"(bl));  // an asm block wrote them: keep the matrix core off its last write
+                        } else {
+                            split3(y, bh, bm, bl);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
+                for (int q = 0; q < NPROD; ++q) {
                     product(0, 3, q);
                     product(1, 3, q);
                 }
@@ -704,7 +826,25 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc0), "+v"(acc1));
 #endif
                 if constexpr (N < 4) {
-                    if (valid) {
+                    if constexpr (PAIR && N <= 2) {
+                        // the largest stored value (halo columns hold outputs of real positions too): the scale of the block
+                        // after the next is derived from it.  One exec-masked region for the stores, none for the maximum.
+                        float o0[16], o1[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            o0[r] = relu(acc0[r]);
+                            o1[r] = relu(acc1[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) stage_max = fmaxf(stage_max, fmaxf(fmaxf(o0[r], o0[r + 1]), fmaxf(o1[r], o1[r + 1])));
+                        if (valid) {
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) {
+                                *reinterpret_cast<float2*>(zout + pidx(row_of(r, half), pos, G::SOUT)) = make_float2(o0[r], o0[r + 1]);
+                                *reinterpret_cast<float2*>(zout + pidx(32 + row_of(r, half), pos, G::SOUT)) = make_float2(o1[r], o1[r + 1]);
+                            }
+                        }
+                    } else if (valid) {
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) {  // rows r, r+1 are adjacent output channels: one 8-byte store
                             *reinterpret_cast<float2*>(zout + pidx(row_of(r, half), pos, G::SOUT)) =
@@ -726,8 +866,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     if (act4 && valid) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            act4[row_of(r, half) * G::POUT + pos] = relu(acc0[r]);
-                            act4[(32 + row_of(r, half)) * G::POUT + pos] = relu(acc1[r]);
+                            act4[row_of(r, half) * G::POUT + pos] = relu(acc0[r]) * pc.inv_out;
+                            act4[(32 + row_of(r, half)) * G::POUT + pos] = relu(acc1[r]) * pc.inv_out;
                         }
                     }
                 }
@@ -784,12 +924,13 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (KSL) {
         using L = Leftover<N>;
         if (wv >= L::WAVE0 && wv < L::WAVE0 + 4) {
-            leftover_partial_unit<N>(lds, lane, wv - L::WAVE0, pwo.ring[0]);
+            leftover_partial_unit<N, NP>(lds, lane, wv - L::WAVE0, pwo.ring[0], pc.e);
             __builtin_amdgcn_sched_barrier(0);
             load_afrag(w, N + 1, 0, lane, pwo.ring[0]);  // the next block's first operands fly across the barrier
         }
     }
-    if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables);
+    if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables, pc.s_dwb, pc.s_pwb);
+    if constexpr (PAIR && N <= 2) publish_wave_max(lds, N == 1 ? 2 : 0, wv, lane, stage_max);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
             if (wv >= n_tiles && !(KSL && N == 1)) load_block_head(w, N + 1, lane, pwo);  // waves without a unit in this block
@@ -888,7 +1029,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             }
             if (col == 31) {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) poolbuf[wv * CH + (k >> 4) * 32 + row_of(k & 15, half)] = psum[k >> 4][k & 15];
+                for (int k = 0; k < 32; ++k) poolbuf[wv * CH + (k >> 4) * 32 + row_of(k & 15, half)] = psum[k >> 4][k & 15] * pc.inv_out;
             }
         }
     }
@@ -916,7 +1057,10 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
                                                            float* __restrict__ act_arg,
                                                            unsigned long long* __restrict__ stamps_arg,
                                                            const int* __restrict__ ring_hops, StreamPush sp) {
-    static_assert(!STREAM || (MODE >= 4 && !DIAG && !PRECONV), "the fused push exists for the product path only");
+    static_assert(!STREAM || (MODE >= 4 && !DIAG && !PRECONV), "the fused push exists for the product paths only");
+    constexpr bool PAIR = MODE == 5;   // f16-pair arithmetic (kws_split_mfma.h): activations live in LDS in per-clip scaled units
+    constexpr int NP = PAIR ? 2 : 3;
+    static_assert(!PAIR || !PRECONV, "the pre-convolved entry runs the bf16 triple");
     static_assert(!CLUSTER || STREAM, "time-tile clusters exist for the streaming push only");
     float* const act = DIAG ? act_arg : nullptr;
     unsigned long long* const stamps = DIAG ? stamps_arg : nullptr;
@@ -952,6 +1096,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     constexpr bool SPLIT = MODE >= 4;
     PwOperands<MODE> wa;            // pointwise operands of the running block
     int hops_before = 0;            // STREAM: pushes before this one
+    // PAIR: exponents of the clip's scales.  kx: features; ky[n]: block n's depthwise output (true units) * 2^ky[n] < 2^15;
+    // sg[n]: the units stage n's accumulators and stored output are in (sg[0]: conv1), = ky[n] + the layer's weight exponent
+    int kx = 0, ky[5] = {0, 0, 0, 0, 0}, sg[5] = {0, 0, 0, 0, 0};
     if constexpr (PRECONV) {
         static_assert(!PRECONV || MODE >= 4, "the pre-convolved entry exists for the product (split) path only");
         const float* z = feat + (size_t)clip * (CH * P0);
@@ -1001,13 +1148,13 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     fetch_block_tables(w, 1, tid, t1);
     __builtin_amdgcn_sched_barrier(0);
     float a1[SPLIT ? 1 : 50];       // conv1 weights of this wave's output-channel tile (f32 MFMA A operands)
-    uintx4 c1f[SPLIT ? 7 : 1][3];   // the same as bf16 pieces (split path)
+    uintx4 c1f[SPLIT ? 7 : 1][NP];  // the same as bf16 pieces / f16 pairs (split paths)
     if constexpr (SPLIT) {
-        const uintx4* src = reinterpret_cast<const uintx4*>(w.c1_split) + (size_t)(wv & 1) * (7 * 3 * 64) + lane;
+        const uintx4* src = reinterpret_cast<const uintx4*>(PAIR ? w.c1_pair : w.c1_split) + (size_t)(wv & 1) * (7 * NP * 64) + lane;
 #pragma unroll
         for (int kb = 0; kb < 7; ++kb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) c1f[kb][p] = src[(kb * 3 + p) * 64];
+            for (int p = 0; p < NP; ++p) c1f[kb][p] = src[(kb * NP + p) * 64];
     } else if constexpr (MFMA) {
         const int half = lane >> 5, col = lane & 31, ct = wv & 1;
 #pragma unroll
@@ -1015,6 +1162,12 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         load_pointwise(w, 1, lane, wa);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PAIR) {  // the clip's largest |feature| (the row the streaming front end adds is looked at after the barrier)
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < FV; ++k) m = fmaxf(m, fabsf(fv[k]));
+        publish_wave_max(lds, 0, wv, lane, m);
+    }
     if constexpr (STREAM) {
         // One barrier: the zero fill touches only the padding, the scatter only the interior, and the new frame's row is
         // written by wavefront 0 alone, straight from the cepstrum registers of its one-frame front end (scratch and tables
@@ -1031,7 +1184,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
             const int r = i / FEAT_W - 2, c = i % FEAT_W - 2;
             if (!((unsigned)r < (unsigned)IN_T && (unsigned)c < (unsigned)IN_F)) featp[i] = 0.f;
         }
-        store_block_tables(lds, 1, tid, t1);
+        if constexpr (!PAIR) store_block_tables(lds, 1, tid, t1);
 #pragma unroll
         for (int k = 0; k < FV; ++k) {
             const int i = tid + k * NT;
@@ -1040,7 +1193,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         __syncthreads();
     } else {
     for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
-    store_block_tables(lds, 1, tid, t1);
+    if constexpr (!PAIR) store_block_tables(lds, 1, tid, t1);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FV; ++k) {
@@ -1049,12 +1202,30 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     }
     __syncthreads();
     }
+    if constexpr (PAIR) {
+        // Scales of conv1 and block 1, from the clip's largest |feature| Mx and bounds that hold for any input (kws_internal.h):
+        // features * 2^kx < 2^15; conv1's accumulators and stored output are in units 2^sg0; block 1's depthwise output
+        // (true units) is below dw_abs (c1_abs Mx + c1_bmax) + dw_bmax, which fixes its operand scale 2^ky1 and its units.
+        float mxf = read_stage_max(lds, 0, 1);
+        if constexpr (STREAM) {
+            // the window's newest row exists only in the workgroup whose wavefront 0 computed it (the last time tile); in the
+            // others its cells are never written (their ranges stop short of it)
+            if (row_new >= 0 && cl_tile == cl_n - 1)
+                for (int c = 0; c < IN_F; ++c) mxf = fmaxf(mxf, fabsf(featp[(row_new + 2) * FEAT_W + 2 + c]));
+        }
+        kx = pow2_exp_for(mxf);
+        sg[0] = kx + w.k_c1;
+        const float bz0 = (w.c1_abs * mxf + w.c1_bmax) * 1.001f;
+        ky[1] = pow2_exp_for((w.dw_abs[0] * bz0 + w.dw_bmax[0]) * 1.001f);
+        sg[1] = ky[1] + w.k_pw[0];
+        store_block_tables(lds, 1, tid, t1, pow2f(sg[0]), pow2f(sg[1]));  // (read in block 1, behind conv1's barrier)
+    }
     stamp();  // 1: features staged
 
     if constexpr (SPLIT) {
-        conv1_phase_split<CLUSTER>(w, lds, tid, c1f, rg0);
+        conv1_phase_split<CLUSTER, NP>(w, lds, tid, c1f, rg0, pow2f(kx), pow2f(sg[0]));
         // the conv1 operands are dead: block 1's first fly across the barrier (wavefronts 4-7: their k-block of the leftover tile)
-        if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER)
+        if constexpr (Leftover<1>::HAS && (MODE == 4 || MODE == 5) && !CLUSTER)
             load_afrag(w, 1, wv >= 4 ? wv - 4 : 0, lane, wa.ring[0]);
         else
             load_block_head(w, 1, lane, wa);
@@ -1066,47 +1237,87 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     __syncthreads();
     stamp();  // 3: conv1 barrier
     float* a = act ? act + (size_t)clip * KWS_ACT_FLOATS_PER_CLIP : nullptr;
+    constexpr bool KSL_ON = (MODE == 4 || MODE == 5) && !CLUSTER;  // the leftover tiles of blocks 1 / 2 are K-split
+    // PAIR: the planes hold activations * 2^sg[n]; the dumps (diagnostics) go out in true units
     if (a) {
-        for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)];
+        const float u = PAIR ? pow2f(-sg[0]) : 1.f;
+        for (int i = tid; i < CH * P0; i += NT) a[i] = lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)] * u;
         a += CH * P0;
     }
-
-    block_phase<1, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg1);
+    PairCtx pc;
+    if constexpr (PAIR) {
+        // conv1's largest output is known now: it bounds block 1's output, which fixes block 2's operand scale and units --
+        // two layers ahead, so that block 2's tables can be stored (scaled) while block 1 runs
+        const float mz = read_stage_max(lds, 1, 1) * pow2f(-sg[0]);
+        const float bz = (w.pw_abs[0] * ((w.dw_abs[0] * mz + w.dw_bmax[0]) * 1.001f) + w.pw_bmax[0]) * 1.001f;
+        ky[2] = pow2_exp_for((w.dw_abs[1] * bz + w.dw_bmax[1]) * 1.001f);
+        sg[2] = ky[2] + w.k_pw[1];
+        pc.e = pow2f(ky[1] - sg[0]);
+        pc.s_dwb = pow2f(sg[1]);
+        pc.s_pwb = pow2f(sg[2]);
+    }
+    block_phase<1, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg1, pc);
     stamp();  // 4: block 1 units of wave 0 done
     __syncthreads();
-    if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER) {
-        leftover_combine<1>(lds, tid);
+    if constexpr (Leftover<1>::HAS && KSL_ON) {
+        leftover_combine<1, PAIR>(lds, tid);
         __syncthreads();
     }
     stamp();  // 5: block 1 barrier
     if (a) {
+        const float u = PAIR ? pow2f(-sg[1]) : 1.f;
         for (int i = tid; i < CH * Blk<1>::POUT; i += NT)
-            a[i] = lds[OFF_Z1 + pidx(i / Blk<1>::POUT, i % Blk<1>::POUT, Blk<1>::SOUT)];
+            a[i] = lds[OFF_Z1 + pidx(i / Blk<1>::POUT, i % Blk<1>::POUT, Blk<1>::SOUT)] * u;
         a += CH * Blk<1>::POUT;
     }
-    block_phase<2, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg2);
+    if constexpr (PAIR) {
+        // block 2 reads block 1's interior and its ring (relu(bias) <= pw_bmax)
+        const float mz = fmaxf(read_stage_max(lds, 2, (Leftover<1>::HAS && KSL_ON) ? 2 : 1) * pow2f(-sg[1]), w.pw_bmax[0]);
+        const float bz = (w.pw_abs[1] * ((w.dw_abs[1] * mz + w.dw_bmax[1]) * 1.001f) + w.pw_bmax[1]) * 1.001f;
+        ky[3] = pow2_exp_for((w.dw_abs[2] * bz + w.dw_bmax[2]) * 1.001f);
+        sg[3] = ky[3] + w.k_pw[2];
+        pc.e = pow2f(ky[2] - sg[1]);
+        pc.s_dwb = pow2f(sg[2]);
+        pc.s_pwb = pow2f(sg[3]);
+    }
+    block_phase<2, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg2, pc);
     stamp();  // 6
     __syncthreads();
-    if constexpr (Leftover<2>::HAS && MODE == 4 && !CLUSTER) {
-        leftover_combine<2>(lds, tid);
+    if constexpr (Leftover<2>::HAS && KSL_ON) {
+        leftover_combine<2, PAIR>(lds, tid);
         __syncthreads();
     }
     stamp();  // 7
     if (a) {
+        const float u = PAIR ? pow2f(-sg[2]) : 1.f;
         for (int i = tid; i < CH * Blk<2>::POUT; i += NT)
-            a[i] = lds[OFF_Z2 + pidx(i / Blk<2>::POUT, i % Blk<2>::POUT, Blk<2>::SOUT)];
+            a[i] = lds[OFF_Z2 + pidx(i / Blk<2>::POUT, i % Blk<2>::POUT, Blk<2>::SOUT)] * u;
         a += CH * Blk<2>::POUT;
     }
-    block_phase<3, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg3);
+    if constexpr (PAIR) {
+        const float mz = fmaxf(read_stage_max(lds, 0, (Leftover<2>::HAS && KSL_ON) ? 2 : 1) * pow2f(-sg[2]), w.pw_bmax[1]);
+        const float bz = (w.pw_abs[2] * ((w.dw_abs[2] * mz + w.dw_bmax[2]) * 1.001f) + w.pw_bmax[2]) * 1.001f;
+        ky[4] = pow2_exp_for((w.dw_abs[3] * bz + w.dw_bmax[3]) * 1.001f);
+        sg[4] = ky[4] + w.k_pw[3];
+        pc.e = pow2f(ky[3] - sg[2]);
+        pc.s_dwb = pow2f(sg[3]);
+        pc.s_pwb = pow2f(sg[4]);
+    }
+    block_phase<3, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg3, pc);
     stamp();  // 8
     __syncthreads();
     stamp();  // 9
     if (a) {
+        const float u = PAIR ? pow2f(-sg[3]) : 1.f;
         for (int i = tid; i < CH * Blk<3>::POUT; i += NT)
-            a[i] = lds[OFF_Z3 + pidx(i / Blk<3>::POUT, i % Blk<3>::POUT, Blk<3>::SOUT)];
+            a[i] = lds[OFF_Z3 + pidx(i / Blk<3>::POUT, i % Blk<3>::POUT, Blk<3>::SOUT)] * u;
         a += CH * Blk<3>::POUT;
     }
-    block_phase<4, MODE, CLUSTER>(w, lds, tid, wa, a ? a + CH : nullptr, rg4);  // block 4's output follows the pooled means
+    if constexpr (PAIR) {
+        pc.e = pow2f(ky[4] - sg[3]);
+        pc.inv_out = pow2f(-sg[4]);
+    }
+    block_phase<4, MODE, CLUSTER>(w, lds, tid, wa, a ? a + CH : nullptr, rg4, pc);  // block 4's output follows the pooled means
     stamp();  // 10
     // The classifier row of lane c (wavefront 0) and the ring bias of channel tid are requested BEFORE the barrier:
     // their L2 round trips pass while the workgroup waits for its slowest wavefront, instead of sitting exposed at
@@ -1245,7 +1456,10 @@ hipError_t dscnn_init_device() {
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, true>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true>),
-                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true, true>)};
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true, true>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false, false, true>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false, false, true, true>)};
     for (const void* k : kernels) {
         hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -1301,14 +1515,24 @@ hipError_t launch_conv1_general(hipStream_t s, const float* d_x, int B, int C_in
 }
 
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
-                               float* d_logits, int32_t* d_label) {
+                               float* d_logits, int32_t* d_label, bool pair) {
     static_assert(sizeof(float) * (size_t)(LDS_FLOATS - OFF_Z2) >= 16 * 1024 + STREAM_F64_BYTES, "room for the one-frame front end's tables and scratch");
-    if (sp.cluster > 1)
-        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true, true>), dim3(n_streams * sp.cluster), dim3(NT), LDS_FLOATS * sizeof(float),
-                           s, w, d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
-    else
-        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true>), dim3(n_streams), dim3(NT), LDS_FLOATS * sizeof(float), s, w,
-                           d_feat_ring, n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+    const size_t lds = LDS_FLOATS * sizeof(float);
+    if (sp.cluster > 1) {
+        if (pair)
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<5, false, false, true, true>), dim3(n_streams * sp.cluster), dim3(NT), lds, s, w, d_feat_ring,
+                               n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+        else
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true, true>), dim3(n_streams * sp.cluster), dim3(NT), lds, s, w, d_feat_ring,
+                               n_streams, d_logits, d_label, nullptr, nullptr, nullptr, sp);
+    } else {
+        if (pair)
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<5, false, false, true>), dim3(n_streams), dim3(NT), lds, s, w, d_feat_ring, n_streams, d_logits,
+                               d_label, nullptr, nullptr, nullptr, sp);
+        else
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, false, true>), dim3(n_streams), dim3(NT), lds, s, w, d_feat_ring, n_streams, d_logits,
+                               d_label, nullptr, nullptr, nullptr, sp);
+    }
     return hipGetLastError();
 }
 
@@ -1334,6 +1558,12 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
                 hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
             else
                 hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
+            break;
+        case 5:
+            if (d_act || d_stamps)
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<5, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
+            else
+                hipLaunchKernelGGL((kws_dscnn_fwd_kernel<5, false>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag);
             break;
         case 6: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<6>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;
         default: hipLaunchKernelGGL(kws_dscnn_fwd_kernel<1>, dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, d_act, d_stamps, d_ring_hops, lag); break;

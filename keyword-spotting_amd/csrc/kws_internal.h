@@ -150,6 +150,15 @@ struct DscnnWeights {
     int in_channels;           // 1: the fused kernel computes conv1 itself; > 1: kws_conv1_general_kernel + the PRECONV entry
     const float* c1_general;   // [ci][100][64]  conv1 weights as [ci][tap][cout] (multi-channel models and the composed any-map path)
     const float* raw;          // the state_dict blob as loaded (torch layouts): the composed path's depthwise / pointwise operands
+    // f16-pair arithmetic (KWS_PW_PAIR_F16, kws_dscnn.hip): every weight scaled by its layer's power of two 2^k (max |w| 2^k <
+    // 2^15) as hi = f16(w 2^k), lo = f16(w 2^k - hi); same fragment orders as the bf16 images with two pieces
+    const uint32_t* pw_pair;   // [4][ct 2][m 4][piece 2][lane 64][4]
+    const uint32_t* c1_pair;   // [ct 2][kb 7][piece 2][lane 64][4]
+    int k_c1, k_pw[4];         // the layers' weight-scale exponents
+    // bounds the per-clip activation scales are derived from: |conv1 out| <= c1_abs max|x| + c1_bmax; per block
+    // |depthwise out| <= dw_abs max|in| + dw_bmax, |pointwise out| <= pw_abs max|depthwise out| + pw_bmax (row sums of |w|,
+    // maximised over output channels, rounded up)
+    float c1_abs, c1_bmax, dw_abs[4], dw_bmax[4], pw_abs[4], pw_bmax[4];
 };
 
 hipError_t dscnn_init_device();
@@ -173,7 +182,7 @@ struct StreamPush {
     int* h_flag;             // pinned host: the push count whose results are complete in h_logits / h_label
 };
 hipError_t launch_dscnn_stream(hipStream_t s, const DscnnWeights& w, const StreamPush& sp, float* d_feat_ring, int n_streams,
-                               float* d_logits, int32_t* d_label);
+                               float* d_logits, int32_t* d_label, bool pair);
 hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_feat, int B, float* d_logits,
                         int32_t* d_label, float* d_act, int mode, unsigned long long* d_stamps = nullptr,
                         const int* d_ring_hops = nullptr, bool preconv = false, int frames_lag = 3);

@@ -58,5 +58,54 @@ __device__ __forceinline__ floatx16 mfma_bf16(const uintx4& a, const uintx4& b, 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- f16 pairs ---------------------------------------------------------------------------------------------------
+// An f32 operand x, scaled by a power of two e into f16's range, as hi = f16(x e) and a second f16 piece for the residual
+// x e - hi (exact in f32).  f16 x f16 products are exact in the matrix core's f32 accumulate and the matrix core honours
+// f16 SUBNORMAL inputs (tools/mfma_f16_denorm_probe.hip), so hi*hi + hi*lo + lo*hi reproduces the f32 product to 2^-22
+// relative or 2^-25 absolute (in scaled units), whichever is larger: three MFMAs per k-block instead of the six of the
+// three-way bf16 split.  Two flavours of the residual piece: PLAIN lo = f16(x e - hi) goes to the same accumulator as
+// hi*hi (kws_dscnn.hip); SCALED lo' = f16((x e - hi) 2^11) goes to a second accumulator (kws_cnntrad.hip).
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx16 mfma_f16(const uintx4& a, const uintx4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
+}
+// (y0, y1) * e -> one dword of hi pieces and one of PLAIN lo pieces; e is wavefront-uniform (a scalar register).  Six
+// full-rate VALU instructions for two values: v_fma_mixlo/hi_f16 convert with the scale folded in and write the two halves
+// of a dword in place, v_fma_mix_f32 forms y e - hi with the f16 piece read as an operand.
+__device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_t& hi, uint32_t& lo) {
+    float t0, t1;
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
+        "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, 0"
+        : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1)
+        : "v"(y0), "v"(y1), "s"(e));
+    hi = h;
+    lo = l;
+}
+__device__ __forceinline__ void split_pair8(const float (&y)[8], float e, uintx4& hi, uintx4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t h, l;
+        split_pair2(y[2 * i], y[2 * i + 1], e, h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+// the power of two s with bound * s < 2^15 (bound >= 0), as an exponent kept within +-100 (so that 2^-k is a normal float too)
+__device__ __forceinline__ int pow2_exp_for(float bound) {
+    const int e = (int)((__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu);  // bound < 2^(e - 126)
+    const int k = 141 - e;
+    return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) {
+    k = k < -126 ? -126 : (k > 127 ? 127 : k);
+    return __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
+}
+
 }  // namespace
 }  // namespace kws

@@ -25,7 +25,9 @@ FE_REFINE_SPAN_DEFAULT = 12.0  # KWS_FE_REFINE_SPAN_DEFAULT: log-mel span beyond
 FE_F32, FE_F64 = 0, 1  # KWS_FE_F32 (default: the fast float32 front end) / KWS_FE_F64 (float64 after framing, as psf)
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64 + 64 * 477  # KWS_ACT_FLOATS_PER_CLIP
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32
-PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16 (default): exact three-way bf16 split, six bf16 MFMAs per f32 product
+PW_SPLIT_BF16 = 4   # KWS_PW_SPLIT_BF16: exact three-way bf16 split, six bf16 MFMAs per f32 product
+PW_PAIR_F16 = 5     # KWS_PW_PAIR_F16 (default): f16 pairs with per-clip power-of-two scales, three f16 MFMAs per f32 product
+PW_DEFAULT = PW_PAIR_F16
 
 _c_ctx = C.c_void_p
 _i16p, _f32p, _i32p = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers

@@ -350,7 +350,7 @@ def golden_case(dscnn_golden, e2e_golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["he", "n01", "default"])
-@pytest.mark.parametrize("use_mfma", [0, 1, 4])  # VALU cross-check, f32 MFMA, split-bf16 MFMA
+@pytest.mark.parametrize("use_mfma", [0, 1, 4, 5])  # VALU cross-check, f32 MFMA, split-bf16 MFMA, f16-pair MFMA
 def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, e2e_golden, tag, use_mfma):
     blob, x_np, ref_logits, ref_label = golden_case(dscnn_golden, e2e_golden, tag)
     ctx.load_dscnn(blob, 12)
@@ -382,7 +382,7 @@ def test_dscnn_layers_and_logits(native, ctx, dev, dscnn_golden, e2e_golden, tag
         assert np.array_equal(labels.cpu().numpy(), ref_label)
 
 
-@pytest.mark.parametrize("use_mfma", [0, 1, 4])
+@pytest.mark.parametrize("use_mfma", [0, 1, 4, 5])
 def test_argmax_ties_first_maximum_wins(native, ctx, dev, e2e_golden, use_mfma):
     """torch.max(outputs, 1) returns the first maximum (kws/libs/training.py:371).  tie_all: twelve identical class
     rows -> every logit ties -> label 0 for every input; tie_pair: row 11 is a copy of row lo -> wherever lo wins the two
@@ -395,8 +395,10 @@ def test_argmax_ties_first_maximum_wins(native, ctx, dev, e2e_golden, use_mfma):
         ctx.load_dscnn(g[f"{tag}.blob"], 12)
         logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
         labels = torch.empty((B,), dtype=torch.int32, device=dev)
-        if use_mfma == 4:
-            ctx.forward_f32(x, logits, labels)  # the product instantiation
+        if use_mfma in (4, 5):
+            ctx.set_pointwise_math(use_mfma)
+            ctx.forward_f32(x, logits, labels)  # the product instantiations
+            ctx.set_pointwise_math(native.PW_DEFAULT)
         else:
             act = torch.zeros((B, native.ACT_FLOATS_PER_CLIP), dtype=torch.float32, device=dev)
             ctx.forward_debug_f32(x, logits, labels, act, use_mfma=use_mfma)
@@ -572,7 +574,7 @@ def test_pointwise_math_settings_agree(native, ctx, dev, dscnn_golden):
     ctx.load_dscnn(g["n01.blob"], 12)
     x = torch.from_numpy(g["x"]).to(dev)
     out = {}
-    for math in (native.PW_SPLIT_BF16, native.PW_F32):
+    for math in (native.PW_SPLIT_BF16, native.PW_F32, native.PW_PAIR_F16):
         ctx.set_pointwise_math(math)
         logits = torch.empty((x.shape[0], 12), dtype=torch.float32, device=dev)
         labels = torch.empty((x.shape[0],), dtype=torch.int32, device=dev)
@@ -583,9 +585,10 @@ def test_pointwise_math_settings_agree(native, ctx, dev, dscnn_golden):
         assert np.array_equal(out[math][1], g["n01.label"])
     scale = max(1.0, float(np.abs(g["n01.logits"]).max()))
     assert np.abs(out[native.PW_SPLIT_BF16][0] - out[native.PW_F32][0]).max() <= 1e-5 * scale
+    assert np.abs(out[native.PW_SPLIT_BF16][0] - out[native.PW_PAIR_F16][0]).max() <= 1e-5 * scale
     with pytest.raises(ModelError):
         ctx.set_pointwise_math(2)
-    ctx.set_pointwise_math(native.PW_SPLIT_BF16)
+    ctx.set_pointwise_math(native.PW_DEFAULT)
 
 
 # ------------------------------------------------------------------------------------------- fused wav -> label

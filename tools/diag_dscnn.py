@@ -34,7 +34,7 @@ def main():
     ctx.mfcc_i16(wav, feat)
     logits = torch.empty((B, 12), dtype=torch.float32, device=dev)
     stamps = torch.zeros((B, 16), dtype=torch.int64, device=dev)
-    label = {0: "VALU cross-check", 1: "product", 2: "ablation: matrix core only", 3: "ablation: stencil only", 4: "split-bf16 MFMA", 6: "ablation of 4: split + matrix core, no stencil"}
+    label = {0: "VALU cross-check", 1: "product", 2: "ablation: matrix core only", 3: "ablation: stencil only", 4: "split-bf16 MFMA", 5: "f16-pair MFMA", 6: "ablation of 4: split + matrix core, no stencil"}
     for mode in modes:
         for _ in range(3):
             ctx.forward_stamps_f32(feat, logits, stamps, mode)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostics (GPU box): time kws_forward_f32 (DS-CNN alone) for the library selected by KWS_HIP_LIB."""
+"""Diagnostics (GPU box): time kws_forward_f32 (DS-CNN alone) for the library selected by KWS_HIP_LIB.
+
+    python tools/time_dscnn.py [clips = 4096] [pointwise math: 4 = bf16 triple, 5 = f16 pair, 1 = f32 MFMA; default = the context's]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +12,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda", 0)
 ctx = _native.Context(0); ctx.use_torch_stream()
 ctx.load_dscnn(bench.bench_weights()[0], 12)
+if len(sys.argv) > 2:
+    ctx.set_pointwise_math(int(sys.argv[2]))
 wav = torch.from_numpy(bench.synth_clips(B, 0)).to(dev)
 feat = torch.empty((B, 1, 99, 10), dtype=torch.float32, device=dev)
 ctx.mfcc_i16(wav, feat)
@@ -24,4 +28,4 @@ for rep in range(5):
     for _ in range(40): ctx.forward_f32(feat, logits, labels)
     t1.record(); torch.cuda.synchronize()
     best = min(best, t0.elapsed_time(t1) / 40)
-print(f"{os.environ.get('KWS_HIP_LIB', 'default'):50s} dscnn best-of-5 {best:.4f} ms  checksum {float(logits.double().sum()):.6f}")
+print(f"{os.environ.get('KWS_HIP_LIB', 'default'):40s} math {sys.argv[2] if len(sys.argv) > 2 else 'default'}  dscnn best-of-5 {best:.4f} ms  checksum {float(logits.double().sum()):.6f}")
