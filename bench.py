@@ -50,8 +50,9 @@ MFCC_FLOP_PER_CLIP = 1.4e6
 PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E spec peak
 PEAK_BF16_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: dense bf16 MFMA
-# bf16 MFMA work the split path executes per clip: (42 block units x 48 + 10 conv1 units x 42) MFMAs of 32x32x16
-DSCNN_EXECUTED_BF16_FLOP_PER_CLIP = (42 * 48 + 10 * 42) * 32 * 32 * 16 * 2
+# 16-bit MFMA work the product path executes per clip on f16 pairs (three piece products per f32 k-block; the bf16 triple
+# executes six): (42 block units x 24 + 10 conv1 units x 21) MFMAs of 32x32x16
+DSCNN_EXECUTED_BF16_FLOP_PER_CLIP = (42 * 24 + 10 * 21) * 32 * 32 * 16 * 2
 # cnn-trad-fpool3 (build-defined): the two convolutions of kws_cnntrad_conv_kernel / all five layers
 CNNTRAD_CONV_FLOP_PER_CLIP = 2 * (99 * 10 * 64 * 160 + 297 * 64 * 2560)
 CNNTRAD_FLOP_PER_CLIP = CNNTRAD_CONV_FLOP_PER_CLIP + 2 * (19008 * 32 + 32 * 128 + 128 * NUM_CLASSES)
@@ -399,10 +400,11 @@ def dscnn_roofline(_native, launches, avg_ms, B, workload="ds-cnn"):
         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/pmc_traffic.json)",
         "algorithmic_bytes_per_launch": B * (99 * 10 * 4 + 52), "avg_kernel_ms": avg_ms, "launches": launches, "launches_note": "launches timed with HIP events inside the timed region (every --prof-every-th launch)",
         "flop_per_clip": DSCNN_FLOP_PER_CLIP,
-        "math": "f32 in / f32 out; conv1 and the four 1x1 convolutions run on v_mfma_f32_32x32x16_bf16 as exact "
-                "three-way bf16 splits (6 MFMAs per f32 product, f32 accumulate); achieved/peak/frac price the ALGORITHMIC "
-                "f32 flops against the f32 MFMA peak the dtype names (a courtesy figure: this formulation could exceed it); "
-                "bf16_pipe prices the executed bf16 MFMA work against the pipe it runs on -- the engineering number",
+        "math": "f32 in / f32 out; conv1 and the four 1x1 convolutions run on v_mfma_f32_32x32x16_f16 with every operand as an f16 pair "
+                "(hi + residual, 22 bits) after exact per-clip power-of-two scaling (3 MFMAs per f32 k-block, f32 accumulate; scales from "
+                "measured maxima and rigorous bounds: no overflow for any input; KWS_PW_PAIR_F16, the bf16 triple stays selectable); "
+                "achieved/peak/frac price the ALGORITHMIC f32 flops against the f32 MFMA peak the dtype names (a courtesy figure: this "
+                "formulation could exceed it); bf16_pipe prices the executed 16-bit MFMA work against the pipe it runs on -- the engineering number",
         "bf16_pipe": {"executed_tflops": executed, "peak": PEAK_BF16_TFLOPS, "frac": executed / PEAK_BF16_TFLOPS},
         # the two fractions side by side: `frac` (= frac_f32_algorithmic) is the contract's definition, frac_bf16_pipe is the
         # utilisation of the matrix pipe the kernel actually runs on -- the engineering number
@@ -1065,6 +1067,31 @@ def worker(args) -> int:
                     "labels_identical": bool(np.array_equal(gy.cpu().numpy(), golden["he.label"][8:])),
                     "n_classes": int(len(set(golden["he.label"][8:].tolist()))), "clips": int(gw.shape[0]),
                     "source": "tests/golden/e2e_golden.npz: imported reference DS-CNN on the oracle's MFCC of 48 diverse clips"}
+            if world == 1 and not args.no_parity and ctx is not None:
+                # the same step on the exact three-way bf16 split (six MFMAs per f32 k-block), same context, after the timed region
+                pair_logits = logits.clone()
+                ctx.set_pointwise_math(_native.PW_SPLIT_BF16)
+                for _ in range(10):
+                    ctx.infer_i16(wav, logits, labels)
+                ctx.sync()
+                ctx.prof_enable(1)
+                ctx.prof_reset()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    ctx.infer_i16(wav, logits, labels)
+                ctx.sync()
+                dt3 = time.perf_counter() - t0
+                t_ms, t_n = ctx.prof_read(_native.KWS_K_DSCNN)
+                ctx.prof_enable(False)
+                ctx.set_pointwise_math(_native.PW_DEFAULT)
+                sc = max(1.0, float(logits.abs().max().item()))
+                out["bf16_triple_same_context"] = {
+                    "clips_per_s": B * 30 / dt3, "ms_per_step": dt3 / 30 * 1e3, "dscnn_kernel_ms": t_ms / max(t_n, 1),
+                    "max_abs_logit_diff_vs_f16_pair_over_scale": float((pair_logits - logits).abs().max().item()) / sc,
+                    "labels_identical": bool(torch.equal(pair_logits.argmax(dim=1), logits.argmax(dim=1))),
+                    "note": "kws_set_pointwise_math(KWS_PW_SPLIT_BF16): the arithmetic of rounds 1-2, every f32 operand as three bf16 pieces"}
+                ctx.infer_i16(wav, logits, labels)  # leave the default arithmetic's results in the buffers
+                ctx.sync()
             if world == 1 and args.cpu_sample > 0:
                 n = min(args.cpu_sample, B)
                 base, cpu_logits = cpu_baseline(clips[:n], blob)

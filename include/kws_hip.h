@@ -201,12 +201,17 @@ int kws_ingest_config(kws_ctx* ctx, int chunk_clips, int n_slots, int pack_threa
  * allocates and must not happen inside stream capture). */
 int kws_reserve(kws_ctx* ctx, int max_batch);
 
-/* Arithmetic of the 1x1 (pointwise) convolutions on the matrix cores -- replaces nothing in the reference
- * (torch's f32 conv2d, kws/libs/models.py:104-106); both settings keep the logits within 1e-4 of it.
- *   KWS_PW_SPLIT_BF16 (default): every f32 operand is split exactly into three bf16 pieces (hi + mid + lo == x)
+/* Arithmetic of conv1 and the 1x1 (pointwise) convolutions on the matrix cores -- replaces nothing in the reference
+ * (torch's f32 conv2d, kws/libs/models.py:104-106); every setting keeps the logits within 1e-4 of it.
+ *   KWS_PW_PAIR_F16 (default): every f32 operand, after an exact power-of-two scaling into f16's range, as an f16 pair
+ *     hi + lo (22 significant bits); three v_mfma_f32_32x32x16_f16 per k-block, f32 accumulate.  Weights are scaled per
+ *     layer at load time, activations per CLIP: the kernel keeps them in LDS in power-of-two units whose exponents it derives,
+ *     two layers ahead, from the measured maximum of an earlier stage and bounds that hold for any input -- nothing can
+ *     overflow, and logits differ from a float64 evaluation by what a plain f32 evaluation differs by.
+ *   KWS_PW_SPLIT_BF16: every f32 operand is split exactly into three bf16 pieces (hi + mid + lo == x)
  *     and the six piece products of combined order <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16;
  *     each bf16 x bf16 product is exact, the dropped terms are <= 2^-24 relative -- the size of one f32
- *     rounding -- and the bf16 matrix pipe runs beside the VALU that evaluates the depthwise stencil.
+ *     rounding.  Twice the matrix instructions of the pair; the multi-channel entry (input_channels > 1) always uses it.
  *   KWS_PW_F32: v_mfma_f32_32x32x2_f32 (shares the FP32 datapath with the VALU; slower).
  * Changing it invalidates a captured streaming graph (re-captured on the next push). */
 #define KWS_PW_F32 1

@@ -8,10 +8,14 @@
 //   4 x { depthwise 3x3 pad 1 ; pointwise 1x1 *padding=1* ; ReLU }  -> 64 x (49x5, 51x7, 53x9, 55x11)
 //   global average pool, Linear(64 -> C), argmax (first maximum wins)
 //
-// Two arithmetic routes for the GEMMs, same f32 results (include/kws_hip.h, kws_set_pointwise_math):
-//   split-bf16 (product): every f32 operand = hi + mid + lo, three bf16 pieces that reproduce it exactly; the six
-//     piece products of combined order <= 2 on v_mfma_f32_32x32x16_bf16 (f32 accumulate) give the f32 product to
-//     2^-24.  16x the f32 MFMA rate, and the bf16 pipe runs beside the VALU (the f32 MFMA shares its datapath).
+// Three arithmetic routes for the GEMMs, same f32-grade results (include/kws_hip.h, kws_set_pointwise_math):
+//   f16 pairs (product, MODE 5): every f32 operand, scaled by a per-clip power of two, = hi + lo, two f16 pieces (22 bits);
+//     three piece products on v_mfma_f32_32x32x16_f16 into one f32 accumulator.  The activations live in LDS in per-clip
+//     power-of-two units; their exponents are decided two layers ahead from measured maxima and weight-derived bounds, so no
+//     input overflows f16 (PairCtx, kws_dscnn_fwd_kernel).
+//   split-bf16 (MODE 4, the product path of rounds 1-2): every f32 operand = hi + mid + lo, three bf16 pieces that reproduce it
+//     exactly; the six piece products of combined order <= 2 on v_mfma_f32_32x32x16_bf16 (f32 accumulate) give the f32 product
+//     to 2^-24.  16x the f32 MFMA rate, and the 16-bit matrix pipe runs beside the VALU (the f32 MFMA shares its datapath).
 //   f32: v_mfma_f32_32x32x2_f32.
 // A third variant runs the GEMMs on the VALU: an independent check of the operand mappings (tests only).
 //

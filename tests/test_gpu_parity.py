@@ -565,6 +565,56 @@ def test_forward_entry_matches_debug_entry(ctx, dev, dscnn_golden):
     assert np.array_equal(la.cpu().numpy(), g["n01.label"])
 
 
+def test_dscnn_f16_pair_arithmetic_holds_over_range(native, ctx, dev, e2e_golden):
+    """The default DS-CNN arithmetic (KWS_PW_PAIR_F16: f16 pairs, per-clip power-of-two scales derived two layers ahead from
+    measured maxima and bounds that hold for any input) against a float64 evaluation of the model, over inputs and weights
+    that stress f16's range: feature maps scaled by 1e-3 .. 1e3, all zero, one huge value among tiny ones, half empty,
+    constant; convolution weights x 6 and x 0.1, biases x 200 and zero.  Nothing may overflow: finite logits everywhere,
+    error against float64 within 4 x what torch's own f32 forward shows on the same clip (floor 2e-6 of the logit scale), and
+    within 3e-6 of the scale of the exact three-way bf16 arithmetic on the same context."""
+    torch.manual_seed(41)
+    x = torch.randn(24, 1, 99, 10) * 6.0
+    x[0] = 0.0
+    x[1] *= 1e-3
+    x[2] *= 1e3
+    x[3] *= 40.0
+    x[4, :, 50:] = 0.0
+    x[5] = torch.randn(1, 99, 10) * 0.01
+    x[5, 0, 40, 3] = 3000.0
+    x[6] = 7.5
+    x[7] = -x[7].abs()
+    x[8, :, :, 0] = -36.04365338911715      # the log-energy floor of digital silence in cepstrum 0
+    base = state_from_blob(e2e_golden["he.blob"])
+    for w_gain, b_gain in ((1.0, 1.0), (6.0, 1.0), (0.1, 1.0), (1.0, 200.0), (1.0, 0.0)):
+        state = {k: v.clone() for k, v in base.items()}
+        for k in state:
+            if k.endswith("weight") and not k.startswith("fc"):
+                state[k] = state[k] * (w_gain if "pointwise" in k or k.startswith("conv1") else 1.0)
+            if k.endswith("bias") and not k.startswith("fc"):
+                state[k] = (state[k] + 0.01) * b_gain
+        blob = np.concatenate([state[k].reshape(-1).numpy() for k in o_dscnn.state_shapes(12)]).astype(np.float32)
+        ctx.load_dscnn(blob, 12)
+        ref64 = o_dscnn.forward({k: v.double() for k, v in state.items()}, x.double())
+        ref32 = o_dscnn.forward(state, x)
+        xd = x.to(dev)
+        out = {}
+        for math in (native.PW_PAIR_F16, native.PW_SPLIT_BF16):
+            ctx.set_pointwise_math(math)
+            logits = torch.empty((x.shape[0], 12), dtype=torch.float32, device=dev)
+            ctx.forward_f32(xd, logits, None)
+            ctx.sync()
+            out[math] = logits.cpu().double()
+        ctx.set_pointwise_math(native.PW_DEFAULT)
+        pair, triple = out[native.PW_PAIR_F16], out[native.PW_SPLIT_BF16]
+        assert torch.isfinite(pair).all() and torch.isfinite(triple).all(), (w_gain, b_gain)
+        for i in range(x.shape[0]):
+            scale = max(1.0, float(ref64[i].abs().max()))
+            e_pair = float((pair[i] - ref64[i]).abs().max())
+            e_f32 = float((ref32[i].double() - ref64[i]).abs().max())
+            assert e_pair <= max(4.0 * e_f32, 2e-6 * scale), (w_gain, b_gain, i, e_pair, e_f32, scale)
+            assert float((pair[i] - triple[i]).abs().max()) <= 3e-6 * scale, (w_gain, b_gain, i)
+
+
 def test_pointwise_math_settings_agree(native, ctx, dev, dscnn_golden):
     """KWS_PW_SPLIT_BF16 (default) and KWS_PW_F32 are two arithmetic routes to the same f32 result: both within
     TOL of the reference logits, within 1e-5 of each other, identical labels; unknown settings are refused."""
