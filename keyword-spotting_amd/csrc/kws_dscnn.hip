@@ -210,10 +210,10 @@ __device__ __forceinline__ void publish_wave_max(float* lds, int set, int wv, in
 }
 // the maximum over n_sets consecutive sets (NW values each): two 16-byte reads per set
 __device__ __forceinline__ float read_stage_max(const float* lds, int set0, int n_sets) {
-    static_assert(NW == 8 && OFF_WMAX % 4 == 0, "the stage maxima are read as float4 pairs");
+    static_assert(NW % 4 == 0 && OFF_WMAX % 4 == 0, "the stage maxima are read as float4s");
     float m = 0.f;
     const float4* q = reinterpret_cast<const float4*>(lds + OFF_WMAX + set0 * NW);
-    for (int i = 0; i < 2 * n_sets; ++i) {
+    for (int i = 0; i < (NW / 4) * n_sets; ++i) {
         const float4 v = q[i];
         m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
