@@ -1071,13 +1071,13 @@ def worker(args) -> int:
                 # the same step on the exact three-way bf16 split (six MFMAs per f32 k-block), same context, after the timed region
                 pair_logits = logits.clone()
                 ctx.set_pointwise_math(_native.PW_SPLIT_BF16)
-                for _ in range(10):
+                for _ in range(30):
                     ctx.infer_i16(wav, logits, labels)
                 ctx.sync()
-                ctx.prof_enable(1)
+                ctx.prof_enable(args.prof_every)   # the same event sampling as the timed region
                 ctx.prof_reset()
                 t0 = time.perf_counter()
-                for _ in range(30):
+                for _ in range(40):
                     ctx.infer_i16(wav, logits, labels)
                 ctx.sync()
                 dt3 = time.perf_counter() - t0
@@ -1086,7 +1086,7 @@ def worker(args) -> int:
                 ctx.set_pointwise_math(_native.PW_DEFAULT)
                 sc = max(1.0, float(logits.abs().max().item()))
                 out["bf16_triple_same_context"] = {
-                    "clips_per_s": B * 30 / dt3, "ms_per_step": dt3 / 30 * 1e3, "dscnn_kernel_ms": t_ms / max(t_n, 1),
+                    "clips_per_s": B * 40 / dt3, "ms_per_step": dt3 / 40 * 1e3, "dscnn_kernel_ms": t_ms / max(t_n, 1),
                     "max_abs_logit_diff_vs_f16_pair_over_scale": float((pair_logits - logits).abs().max().item()) / sc,
                     "labels_identical": bool(torch.equal(pair_logits.argmax(dim=1), logits.argmax(dim=1))),
                     "note": "kws_set_pointwise_math(KWS_PW_SPLIT_BF16): the arithmetic of rounds 1-2, every f32 operand as three bf16 pieces"}
