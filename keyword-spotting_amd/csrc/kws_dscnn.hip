@@ -193,6 +193,20 @@ struct PairCtx {
     float s_pwb = 1.f;      // next block's pointwise bias factor = the next block's output units
     float inv_out = 1.f;    // block 4: pooled sums back to true units
 };
+// Units of a stage: its operand exponent ky (operand * 2^ky < 2^15) plus the layer's weight exponent.  The stage's stored
+// output -- bias included, which the operand bound knows nothing about -- must stay a finite float in those units, and every
+// factor derived from them a normal one: 2^sg * bz < 2^100 (bz: bound on the stage's output in true units) and sg <= 120,
+// enforced by LOWERING the operand scale (always safe; it binds only for bias-dominated or vanishing stages).
+__device__ __forceinline__ void cap_units(int& ky, int& sg, int k_w, float bz) {
+    sg = ky + k_w;
+    const int eb = (int)((__builtin_bit_cast(uint32_t, bz) >> 23) & 0xffu) - 126;  // bz < 2^eb
+    int limit = 100 - eb;
+    limit = limit > 120 ? 120 : limit;
+    if (sg > limit) {
+        ky -= sg - limit;
+        sg = limit;
+    }
+}
 // wavefront maximum of non-negative values -> per-wavefront slot (read by everyone after the stage's barrier).  DPP row
 // scans, no LDS round trips: six dependent ds_bpermute exchanges sat at the end of every wavefront's stage, in front of the barrier.
 __device__ __forceinline__ void publish_wave_max(float* lds, int set, int wv, int lane, float mx) {
@@ -1218,10 +1232,11 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
                 for (int c = 0; c < IN_F; ++c) mxf = fmaxf(mxf, fabsf(featp[(row_new + 2) * FEAT_W + 2 + c]));
         }
         kx = pow2_exp_for(mxf);
-        sg[0] = kx + w.k_c1;
         const float bz0 = (w.c1_abs * mxf + w.c1_bmax) * 1.001f;
-        ky[1] = pow2_exp_for((w.dw_abs[0] * bz0 + w.dw_bmax[0]) * 1.001f);
-        sg[1] = ky[1] + w.k_pw[0];
+        cap_units(kx, sg[0], w.k_c1, bz0);
+        const float by1 = (w.dw_abs[0] * bz0 + w.dw_bmax[0]) * 1.001f;
+        ky[1] = pow2_exp_for(by1);
+        cap_units(ky[1], sg[1], w.k_pw[0], (w.pw_abs[0] * by1 + w.pw_bmax[0]) * 1.001f);
         store_block_tables(lds, 1, tid, t1, pow2f(sg[0]), pow2f(sg[1]));  // (read in block 1, behind conv1's barrier)
     }
     stamp();  // 1: features staged
@@ -1254,8 +1269,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         // two layers ahead, so that block 2's tables can be stored (scaled) while block 1 runs
         const float mz = read_stage_max(lds, 1, 1) * pow2f(-sg[0]);
         const float bz = (w.pw_abs[0] * ((w.dw_abs[0] * mz + w.dw_bmax[0]) * 1.001f) + w.pw_bmax[0]) * 1.001f;
-        ky[2] = pow2_exp_for((w.dw_abs[1] * bz + w.dw_bmax[1]) * 1.001f);
-        sg[2] = ky[2] + w.k_pw[1];
+        const float by = (w.dw_abs[1] * bz + w.dw_bmax[1]) * 1.001f;
+        ky[2] = pow2_exp_for(by);
+        cap_units(ky[2], sg[2], w.k_pw[1], (w.pw_abs[1] * by + w.pw_bmax[1]) * 1.001f);
         pc.e = pow2f(ky[1] - sg[0]);
         pc.s_dwb = pow2f(sg[1]);
         pc.s_pwb = pow2f(sg[2]);
@@ -1278,8 +1294,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         // block 2 reads block 1's interior and its ring (relu(bias) <= pw_bmax)
         const float mz = fmaxf(read_stage_max(lds, 2, (Leftover<1>::HAS && KSL_ON) ? 2 : 1) * pow2f(-sg[1]), w.pw_bmax[0]);
         const float bz = (w.pw_abs[1] * ((w.dw_abs[1] * mz + w.dw_bmax[1]) * 1.001f) + w.pw_bmax[1]) * 1.001f;
-        ky[3] = pow2_exp_for((w.dw_abs[2] * bz + w.dw_bmax[2]) * 1.001f);
-        sg[3] = ky[3] + w.k_pw[2];
+        const float by = (w.dw_abs[2] * bz + w.dw_bmax[2]) * 1.001f;
+        ky[3] = pow2_exp_for(by);
+        cap_units(ky[3], sg[3], w.k_pw[2], (w.pw_abs[2] * by + w.pw_bmax[2]) * 1.001f);
         pc.e = pow2f(ky[2] - sg[1]);
         pc.s_dwb = pow2f(sg[2]);
         pc.s_pwb = pow2f(sg[3]);
@@ -1301,8 +1318,9 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     if constexpr (PAIR) {
         const float mz = fmaxf(read_stage_max(lds, 0, (Leftover<2>::HAS && KSL_ON) ? 2 : 1) * pow2f(-sg[2]), w.pw_bmax[1]);
         const float bz = (w.pw_abs[2] * ((w.dw_abs[2] * mz + w.dw_bmax[2]) * 1.001f) + w.pw_bmax[2]) * 1.001f;
-        ky[4] = pow2_exp_for((w.dw_abs[3] * bz + w.dw_bmax[3]) * 1.001f);
-        sg[4] = ky[4] + w.k_pw[3];
+        const float by = (w.dw_abs[3] * bz + w.dw_bmax[3]) * 1.001f;
+        ky[4] = pow2_exp_for(by);
+        cap_units(ky[4], sg[4], w.k_pw[3], (w.pw_abs[3] * by + w.pw_bmax[3]) * 1.001f);
         pc.e = pow2f(ky[3] - sg[2]);
         pc.s_dwb = pow2f(sg[3]);
         pc.s_pwb = pow2f(sg[4]);

@@ -29,6 +29,19 @@ def _exp_for(bound: float) -> int:
     return int(np.clip(15 - int(np.frexp(b)[1]), -100, 100))
 
 
+def _cap_units(ky: int, k_w: int, bz: float):
+    """(ky, sg): the stage's units 2^sg = 2^(ky + k_w), lowered (through ky) until the stage's stored output -- bias included,
+    bounded by bz in true units -- stays below 2^100 in them and sg <= 120 (the kernel's cap_units)."""
+    sg = ky + k_w
+    b = np.float32(bz)
+    eb = int(np.frexp(b)[1]) if b > 0 else -126
+    limit = min(100 - eb, 120)
+    if sg > limit:
+        ky -= sg - limit
+        sg = limit
+    return ky, sg
+
+
 def _pair(a: np.ndarray):
     """hi, lo of already scaled values; asserts the range claim."""
     x = a.astype(np.float32)
@@ -66,23 +79,24 @@ def _forward_pair(state, x):
         xi = x[n:n + 1]
         mx = float(xi.abs().max())
         kx = _exp_for(mx)
-        sg = [kx + k_c1, 0, 0, 0, 0]
+        sg = [0, 0, 0, 0, 0]
         ky = [0, 0, 0, 0, 0]
+        kx, sg[0] = _cap_units(kx, k_c1, (c1_abs * mx + c1_bmax) * 1.001)
         # conv1: im2col of the features times 2^kx, accumulators and stored plane in units 2^sg[0]
         cols = F.unfold(F.pad(xi, (2, 2, 2, 2)), (10, 10), stride=2).numpy()[0]                       # [100, 141]
         acc = _gemm(w1p, _pair(cols * np.float32(2.0 ** kx)))
         z = np.maximum(acc + st["conv1.bias"][:, None] * np.float32(2.0 ** sg[0]), 0).reshape(1, 64, 47, 3)
         # scales of block 1: from the a-priori bound on conv1's output (two layers ahead of the features)
         bz = (c1_abs * mx + c1_bmax) * 1.001
-        ky[1] = _exp_for((blk[0]["dw_abs"] * bz + blk[0]["dw_bmax"]) * 1.001)
-        sg[1] = ky[1] + blk[0]["k_pw"]
+        by = (blk[0]["dw_abs"] * bz + blk[0]["dw_bmax"]) * 1.001
+        ky[1], sg[1] = _cap_units(_exp_for(by), blk[0]["k_pw"], (blk[0]["pw_abs"] * by + blk[0]["pw_bmax"]) * 1.001)
         measured = float(z.max()) * 2.0 ** -sg[0]                                                      # conv1's largest output, true units
         for i, b in enumerate(blk, start=1):
             if i < 4:  # decided at the start of block i for block i + 1: measured max of stage i - 1 (and its ring) -> two bounds
                 m_in = measured if i == 1 else max(measured, blk[i - 2]["pw_bmax"])
                 bz = (b["pw_abs"] * ((b["dw_abs"] * m_in + b["dw_bmax"]) * 1.001) + b["pw_bmax"]) * 1.001
-                ky[i + 1] = _exp_for((blk[i]["dw_abs"] * bz + blk[i]["dw_bmax"]) * 1.001)
-                sg[i + 1] = ky[i + 1] + blk[i]["k_pw"]
+                by = (blk[i]["dw_abs"] * bz + blk[i]["dw_bmax"]) * 1.001
+                ky[i + 1], sg[i + 1] = _cap_units(_exp_for(by), blk[i]["k_pw"], (blk[i]["pw_abs"] * by + blk[i]["pw_bmax"]) * 1.001)
             # depthwise on the scaled plane (its ring = relu(previous pointwise bias) in the same units), bias in the plane's units
             zin = torch.from_numpy(z)
             if i > 1:
@@ -96,6 +110,7 @@ def _forward_pair(state, x):
             h, w_ = y.shape[2], y.shape[3]
             acc = _gemm(b["pwp"], _pair(y.reshape(64, h * w_) * e))
             z = np.maximum(acc + b["pwb"][:, None] * np.float32(2.0 ** sg[i]), 0).reshape(1, 64, h, w_)
+            assert np.isfinite(z).all(), "a stored plane left the float range in its units"
             measured = float(z.max()) * 2.0 ** -sg[i]
         # pool over the interior and the ring of block 4's output, true units
         interior = z.reshape(64, -1).sum(axis=1) * np.float32(2.0 ** -sg[4])
@@ -105,7 +120,8 @@ def _forward_pair(state, x):
     return np.stack(out)
 
 
-@pytest.mark.parametrize("seed,w_gain,b_gain", [(1, 1.0, 1.0), (2, 5.0, 1.0), (3, 0.2, 1.0), (4, 1.0, 100.0), (5, 1.0, 0.0)])
+@pytest.mark.parametrize("seed,w_gain,b_gain", [(1, 1.0, 1.0), (2, 5.0, 1.0), (3, 0.2, 1.0), (4, 1.0, 100.0), (5, 1.0, 0.0),
+                                                  (6, 1e-9, 0.0), (7, 300.0, 1e7)])  # the last two: vanishing / bias-dominated stages
 def test_f16_pair_model_is_f32_grade_and_never_overflows(seed, w_gain, b_gain):
     state = o_dscnn.random_state(seed, std=0.1)
     for k in list(state):

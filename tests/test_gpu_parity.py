@@ -585,7 +585,8 @@ def test_dscnn_f16_pair_arithmetic_holds_over_range(native, ctx, dev, e2e_golden
     x[7] = -x[7].abs()
     x[8, :, :, 0] = -36.04365338911715      # the log-energy floor of digital silence in cepstrum 0
     base = state_from_blob(e2e_golden["he.blob"])
-    for w_gain, b_gain in ((1.0, 1.0), (6.0, 1.0), (0.1, 1.0), (1.0, 200.0), (1.0, 0.0)):
+    # (the last two: every stage's values far below 1 -- the units are capped at 2^120 there -- and far above)
+    for w_gain, b_gain in ((1.0, 1.0), (6.0, 1.0), (0.1, 1.0), (1.0, 200.0), (1.0, 0.0), (1e-9, 0.0), (300.0, 1e6)):
         state = {k: v.clone() for k, v in base.items()}
         for k in state:
             if k.endswith("weight") and not k.startswith("fc"):
