@@ -1210,9 +1210,12 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         }
         __syncthreads();
     } else {
-    for (int i = tid; i < FEAT_H * FEAT_W; i += NT) featp[i] = 0.f;
+    // one barrier: the zero fill touches only the padding cells, the scatter only the interior
+    for (int i = tid; i < FEAT_H * FEAT_W; i += NT) {
+        const int r = i / FEAT_W - 2, c = i % FEAT_W - 2;
+        if (!((unsigned)r < (unsigned)IN_T && (unsigned)c < (unsigned)IN_F)) featp[i] = 0.f;
+    }
     if constexpr (!PAIR) store_block_tables(lds, 1, tid, t1);
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < FV; ++k) {
         const int i = tid + k * NT;
