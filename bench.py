@@ -940,6 +940,8 @@ def worker(args) -> int:
             step = lambda: ctx.infer_cnn_trad_i16(wav, logits, labels)
         else:
             ctx.load_dscnn(blob, NUM_CLASSES)
+            if args.pointwise_math == "triple":
+                ctx.set_pointwise_math(_native.PW_SPLIT_BF16)
             step = lambda: ctx.infer_i16(wav, logits, labels)
         ctx.reserve(B)
         sync = torch.cuda.synchronize
@@ -1042,7 +1044,9 @@ def worker(args) -> int:
                                  f"DS-CNN end to end: batch={B}/GPU synthetic uniform int16 1s/16kHz clips (the batch shape of BASELINE "
                                  "configs[2], the reference's own model -- configs[2]'s literal cnn-trad-fpool3 is under configs.C3)")
                                 + ", device-resident, MFCC(400/160/512, 26 mel, 10 cep) + DS-CNN(12 classes, signal-preserving golden "
-                                  "weights) -> logits+label" + (" [float64 front end]" if args.frontend_math == "f64" else ""), **cfg},
+                                  "weights) -> logits+label" + (" [float64 front end]" if args.frontend_math == "f64" else "")
+                                + (" [DS-CNN on the bf16 triple, not the default arithmetic: roofline.math and bf16_pipe describe the default]"
+                                   if args.pointwise_math == "triple" else ""), **cfg},
                 "roofline": dscnn_roofline(_native, k_n, dscnn_ms, B),
                 "hbm_read": {"bytes_per_clip": BYTES_PER_CLIP, "achieved_GBps_per_gpu": value / world * BYTES_PER_CLIP / 1e9,
                              "frac_of_8TBps": value / world * BYTES_PER_CLIP / PEAK_HBM_BPS},
@@ -1138,6 +1142,9 @@ def parse_args(argv=None):
                     help="ds-cnn: the reference's model (the driver's line); cnn-trad-fpool3: the build-defined model "
                          "BASELINE.json configs[2] names (parity unpinned against the reference, DESIGN.md 4.5); "
                          "mfcc-only: BASELINE.json configs[1], the front end alone, priced against the HBM-read roofline")
+    ap.add_argument("--pointwise-math", choices=["pair", "triple"], default="pair",
+                    help="DS-CNN GEMM arithmetic of the timed steps: pair = KWS_PW_PAIR_F16 (the library's default), triple = KWS_PW_SPLIT_BF16 "
+                         "(rounds 1-2; for counter passes and A/B runs -- the JSON line says which)")
     ap.add_argument("--configs", choices=["all", "none"], default="all",
                     help="all: at N = 1 the ds-cnn line also measures the other BASELINE configurations under `configs`")
     ap.add_argument("--config-steps", type=int, default=100, help="timed steps of each side configuration")

@@ -15,11 +15,13 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = "conv" if "cnntrad_conv" in r["Kernel_Name"] else "dense" if "cnntrad_dense" in r["Kernel_Name"] else None
+        n = r["Kernel_Name"]
+        math = "pair  " if "<true>" in n else "triple"   # kws_cnntrad_*_kernel<H2>
+        k = (math + " conv") if "cnntrad_conv" in n else (math + " dense") if "cnntrad_dense" in n else None
         if k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(os.path.join(out, "summary.txt"), "w") as fh:
     for k, d in agg.items():
         for c, v in sorted(d.items()):
-            line = f"{k:6s} {c:28s} {sum(v)/len(v):16.1f}  (n={len(v)})"
+            line = f"{k:13s} {c:28s} {sum(v)/len(v):16.1f}  (n={len(v)})"
             print(line); fh.write(line + "\n")
 PY

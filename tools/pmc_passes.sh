@@ -7,7 +7,7 @@ set -o pipefail
 OUT=/root/repo/gpurun_out/${1:-pmc}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python /root/repo/bench.py --steps 5 --warmup 1 --spinup 4 --cpu-sample 0 --configs none --no-parity"   # 10 launches of each kernel, 4096 clips each
+BENCH="python /root/repo/bench.py --steps 5 --warmup 1 --spinup 4 --cpu-sample 0 --configs none --no-parity ${KWS_BENCH_EXTRA:-}"   # 10 launches of each kernel, 4096 clips each
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT" -o "$name" -- $BENCH > "$OUT/$name.log" 2>&1 || exit 1; }
 run sq_a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run sq_b SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
