@@ -526,7 +526,7 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
                     }
     }
     // the f16-pair images and the bounds behind the per-clip activation scales (kws_dscnn.hip, KWS_PW_PAIR_F16)
-    DscnnWeights& mw = c->mw;
+    DscnnWeights mw{};  // (a local: the context keeps its old model if the upload below fails)
     if (input_channels == 1) {
         const float sw = pow2_weight_scale(src, 6400);
         int ke;
@@ -635,6 +635,16 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     c->mw.c1_split = reinterpret_cast<const uint32_t*>(d + o_c1s);
     c->mw.pw_pair = reinterpret_cast<const uint32_t*>(d + o_pwp);
     c->mw.c1_pair = reinterpret_cast<const uint32_t*>(d + o_c1p);
+    c->mw.k_c1 = mw.k_c1;
+    c->mw.c1_abs = mw.c1_abs;
+    c->mw.c1_bmax = mw.c1_bmax;
+    for (int b = 0; b < 4; ++b) {
+        c->mw.k_pw[b] = mw.k_pw[b];
+        c->mw.dw_abs[b] = mw.dw_abs[b];
+        c->mw.dw_bmax[b] = mw.dw_bmax[b];
+        c->mw.pw_abs[b] = mw.pw_abs[b];
+        c->mw.pw_bmax[b] = mw.pw_bmax[b];
+    }
     c->mw.fc_w = d + o_fcw;
     c->mw.fc_b = d + o_fcb;
     c->mw.num_classes = num_classes;
