@@ -211,7 +211,7 @@ int kws_reserve(kws_ctx* ctx, int max_batch);
  *   KWS_PW_SPLIT_BF16: every f32 operand is split exactly into three bf16 pieces (hi + mid + lo == x)
  *     and the six piece products of combined order <= 2 are accumulated in f32 by v_mfma_f32_32x32x16_bf16;
  *     each bf16 x bf16 product is exact, the dropped terms are <= 2^-24 relative -- the size of one f32
- *     rounding.  Twice the matrix instructions of the pair; the multi-channel entry (input_channels > 1) always uses it.
+ *     rounding.  Twice the matrix instructions of the pair.
  *   KWS_PW_F32: v_mfma_f32_32x32x2_f32 (shares the FP32 datapath with the VALU; slower).
  * Changing it invalidates a captured streaming graph (re-captured on the next push). */
 #define KWS_PW_F32 1

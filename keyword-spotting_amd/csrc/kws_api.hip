@@ -778,8 +778,7 @@ static int forward_impl(kws_ctx* c, const float* d_feat, int B, float* d_logits,
         // multi-channel input (models.py:125,135): conv1 in its own kernel through the context scratch, then the fused
         // kernel from block 1 on; the diagnostics variants exist for the single-channel model only
         if (d_act || d_stamps || (mode != KWS_PW_SPLIT_BF16 && mode != KWS_PW_PAIR_F16))
-            return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": input_channels > 1 runs on the product kernel only");
-        mode = KWS_PW_SPLIT_BF16;  // the pre-convolved entry computes on the bf16 triple
+            return fail(c, KWS_EUNSUPPORTED, std::string(fn) + ": input_channels > 1 runs on the product kernels only");
         rc = grow_conv_ws(c, (size_t)B * 64 * 141, fn);
         if (rc) return rc;
         HIP_TRY(c, launch_conv1_general(c->stream, d_feat, B, c->mw.in_channels, c->mw.c1_general, c->mw.c1_b, c->d_conv_ws));

@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     static_assert(!STREAM || (MODE >= 4 && !DIAG && !PRECONV), "the fused push exists for the product paths only");
     constexpr bool PAIR = MODE == 5;   // f16-pair arithmetic (kws_split_mfma.h): activations live in LDS in per-clip scaled units
     constexpr int NP = PAIR ? 2 : 3;
-    static_assert(!PAIR || !PRECONV, "the pre-convolved entry runs the bf16 triple");
+    BlockTables t1_pre{};              // PRECONV: block 1's tables between their fetch and their (PAIR: scaled) store
     static_assert(!CLUSTER || STREAM, "time-tile clusters exist for the streaming push only");
     float* const act = DIAG ? act_arg : nullptr;
     unsigned long long* const stamps = DIAG ? stamps_arg : nullptr;
@@ -1120,15 +1120,24 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
     if constexpr (PRECONV) {
         static_assert(!PRECONV || MODE >= 4, "the pre-convolved entry exists for the product (split) path only");
         const float* z = feat + (size_t)clip * (CH * P0);
-        BlockTables t1;
-        fetch_block_tables(w, 1, tid, t1);
-        for (int i = tid; i < CH * P0; i += NT) lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)] = z[i];
+        fetch_block_tables(w, 1, tid, t1_pre);
+        float zmax = 0.f;
+        for (int i = tid; i < CH * P0; i += NT) {
+            const float v = z[i];
+            lds[OFF_Z0 + pidx(i / P0, i % P0, P0 + 2)] = v;
+            zmax = fmaxf(zmax, v);
+        }
         if (tid < CH) {
             lds[OFF_Z0 + pidx(tid, P0, P0 + 2)] = 0.f;
             lds[OFF_Z0 + pidx(tid, P0 + 1, P0 + 2)] = 0.f;
         }
-        store_block_tables(lds, 1, tid, t1);
-        if constexpr (Leftover<1>::HAS && MODE == 4 && !CLUSTER)
+        // PAIR: conv1's output arrives in true units (sg[0] = 0) and nothing bounds it in advance: its largest value is measured
+        // here, block 1's scale and tables follow behind the barrier below (one more barrier than the single-channel path)
+        if constexpr (PAIR)
+            publish_wave_max(lds, 1, wv, lane, zmax);
+        else
+            store_block_tables(lds, 1, tid, t1_pre);
+        if constexpr (Leftover<1>::HAS && (MODE == 4 || MODE == 5) && !CLUSTER)
             load_afrag(w, 1, wv >= 4 ? wv - 4 : 0, lane, wa.ring[0]);  // wavefronts 4-7: their k-block of block 1's leftover tile
         else
             load_block_head(w, 1, lane, wa);
@@ -1267,6 +1276,14 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         a += CH * P0;
     }
     PairCtx pc;
+    if constexpr (PAIR && PRECONV) {
+        const float mz0 = read_stage_max(lds, 1, 1);  // true units
+        const float by1 = (w.dw_abs[0] * mz0 + w.dw_bmax[0]) * 1.001f;
+        ky[1] = pow2_exp_for(by1);
+        cap_units(ky[1], sg[1], w.k_pw[0], (w.pw_abs[0] * by1 + w.pw_bmax[0]) * 1.001f);
+        store_block_tables(lds, 1, tid, t1_pre, 1.f, pow2f(sg[1]));
+        __syncthreads();
+    }
     if constexpr (PAIR) {
         // conv1's largest output is known now: it bounds block 1's output, which fixes block 2's operand scale and units --
         // two layers ahead, so that block 2's tables can be stored (scaled) while block 1 runs
@@ -1483,6 +1500,7 @@ hipError_t dscnn_init_device() {
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<4, false, false, true, true>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5>), reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false>),
+                             reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false, true>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false, false, true>),
                              reinterpret_cast<const void*>(kws_dscnn_fwd_kernel<5, false, false, true, true>)};
     for (const void* k : kernels) {
@@ -1568,8 +1586,11 @@ hipError_t launch_dscnn(hipStream_t s, const DscnnWeights& w, const float* d_fea
     StreamPush lag{};  // the two-launch streaming route: only the hops-per-frame count travels (the window's first row)
     lag.frames_lag = frames_lag;
     const int grid = B;  // one clip per workgroup; one workgroup per CU (160 KiB LDS)
-    if (preconv) {  // d_feat = conv1 output of a multi-channel model (kws_conv1_general_kernel): product path only
-        hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr, StreamPush{});
+    if (preconv) {  // d_feat = conv1 output of a multi-channel model (kws_conv1_general_kernel): product paths only
+        if (mode == 5)
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<5, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr, StreamPush{});
+        else
+            hipLaunchKernelGGL((kws_dscnn_fwd_kernel<4, false, true>), dim3(grid), dim3(NT), lds, s, w, d_feat, B, d_logits, d_label, nullptr, nullptr, nullptr, StreamPush{});
         return hipGetLastError();
     }
     // mode: 0 = VALU cross-check of the GEMMs, 1 = product path, 2 / 3 = timing ablations (matrix core only /

@@ -545,6 +545,16 @@ def test_multichannel_model(dev):
     assert err <= min(TOL, 4 * LAYER_RTOL * float(np.abs(g["logits"]).max())), err
     assert np.array_equal(labels.cpu().numpy(), g["label"])
     assert float(g["logits"].std(axis=0).mean()) >= 0.1
+    # the same on the exact bf16 triple (the default above is the f16-pair arithmetic: the pre-convolved entry measures conv1's
+    # maximum while staging it)
+    from kws import _native
+    ctx = m._context(0)
+    ctx.set_pointwise_math(_native.PW_SPLIT_BF16)
+    logits3, labels3 = m.forward(torch.from_numpy(g["x"]).to(dev), return_labels=True)
+    ctx.set_pointwise_math(_native.PW_DEFAULT)
+    assert float(np.abs(logits3.cpu().numpy() - g["logits"]).max()) <= min(TOL, 4 * LAYER_RTOL * float(np.abs(g["logits"]).max()))
+    assert np.array_equal(labels3.cpu().numpy(), g["label"])
+    assert float((logits3 - logits).abs().max()) <= 1e-5 * max(1.0, float(np.abs(g["logits"]).max()))
     with pytest.raises(ModelError):
         m.forward(torch.zeros(2, 1, 99, 10, device=dev))            # wrong channel count
     with pytest.raises(ModelError):
