@@ -789,8 +789,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     }
                     if (j == 7) {
                         if constexpr (PAIR) {
-                            split_pair8(y, pc.e, bh, bl);
-                            asm volatile("s_nop 1" : "+v"(bh), "+v"(bl));  // an asm block wrote them: keep the matrix core off its last write
+                            split_pair8(y, pc.e, bh, bl);  // (the next product reads bl a stencil evaluation later)
                         } else {
                             split3(y, bh, bm, bl);
                         }

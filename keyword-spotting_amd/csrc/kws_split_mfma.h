@@ -87,14 +87,40 @@ __device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_
     hi = h;
     lo = l;
 }
+// Eight values at once, as ONE asm block (four separate blocks get an s_nop from the compiler between each other): the four
+// dwords' instructions are interleaved, so an instruction's source was written four instructions earlier.
 __device__ __forceinline__ void split_pair8(const float (&y)[8], float e, uintx4& hi, uintx4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t h, l;
-        split_pair2(y[2 * i], y[2 * i + 1], e, h, l);
-        hi[i] = h;
-        lo[i] = l;
-    }
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_fma_mixlo_f16 %0, %16, %24, 0\n\t"
+        "v_fma_mixlo_f16 %1, %18, %24, 0\n\t"
+        "v_fma_mixlo_f16 %2, %20, %24, 0\n\t"
+        "v_fma_mixlo_f16 %3, %22, %24, 0\n\t"
+        "v_fma_mixhi_f16 %0, %17, %24, 0\n\t"
+        "v_fma_mixhi_f16 %1, %19, %24, 0\n\t"
+        "v_fma_mixhi_f16 %2, %21, %24, 0\n\t"
+        "v_fma_mixhi_f16 %3, %23, %24, 0\n\t"
+        "v_fma_mix_f32 %8, %16, %24, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %10, %18, %24, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %12, %20, %24, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %14, %22, %24, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %9, %17, %24, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %11, %19, %24, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %13, %21, %24, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %15, %23, %24, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %4, %8, 1.0, 0\n\t"
+        "v_fma_mixlo_f16 %5, %10, 1.0, 0\n\t"
+        "v_fma_mixlo_f16 %6, %12, 1.0, 0\n\t"
+        "v_fma_mixlo_f16 %7, %14, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %4, %9, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %5, %11, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %6, %13, 1.0, 0\n\t"
+        "v_fma_mixhi_f16 %7, %15, 1.0, 0"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(t0), "=&v"(t1), "=&v"(t2),
+          "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "s"(e));
+    hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3;
+    lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3;
 }
 // the power of two s with bound * s < 2^15 (bound >= 0), as an exponent kept within +-100 (so that 2^-k is a normal float too)
 __device__ __forceinline__ int pow2_exp_for(float bound) {
