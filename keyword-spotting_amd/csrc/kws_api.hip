@@ -537,8 +537,22 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
             for (int kb = 0; kb < 7; ++kb)
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
-                        const int co = 32 * ct + (l & 31), f = 8 * kb + j;
-                        const float v = f < 50 ? src[co * 100 + (f / 10 + 5 * (l >> 5)) * 10 + f % 10] : 0.f;
+                        // K order of the pre-split windows (kws_dscnn.hip, conv1_unit_pairwin): half-wave h = l >> 5 takes kernel
+                        // rows 5h .. 5h + 4; kb < 5: kernel row 5h + kb, taps kw = j; kb = 5: taps kw = 8 + (j & 1) of kernel row
+                        // 5h + (j >> 1); kb = 6: taps kw = 8 + j (j < 2) of kernel row 5h + 4, then zeros
+                        const int co = 32 * ct + (l & 31), h5 = 5 * (l >> 5);
+                        int kh = -1, kw = 0;
+                        if (kb < 5) {
+                            kh = h5 + kb;
+                            kw = j;
+                        } else if (kb == 5) {
+                            kh = h5 + (j >> 1);
+                            kw = 8 + (j & 1);
+                        } else if (j < 2) {
+                            kh = h5 + 4;
+                            kw = 8 + j;
+                        }
+                        const float v = kh >= 0 ? src[co * 100 + kh * 10 + kw] : 0.f;
                         uint16_t hb, lb;
                         pair_plain(v * sw, hb, lb);
                         sp[(((size_t)(ct * 7 + kb) * 2 + 0) * 64 + l) * 4 + (j >> 1)] |= (uint32_t)hb << (16 * (j & 1));

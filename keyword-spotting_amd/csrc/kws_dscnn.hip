@@ -469,6 +469,123 @@ __device__ __forceinline__ void conv1_unit_split(const DscnnWeights& w, const fl
     }
 }
 
+// ---- conv1 on f16 pairs from PRE-SPLIT WINDOWS (PAIR only) ---------------------------------------------------------------
+// Gathered and split per unit, conv1's B operand cost four 8-byte LDS reads and twelve VALU instructions per k-block in front
+// of every three (six) MFMAs, and the phase ran at the latency of that chain.  Instead the scaled, zero-padded feature map is
+// split ONCE per clip into LDS (the region block 1's output takes later):
+//   W8[piece][row 0..102][s 0..2]  16 bytes: the eight features (row, 2s .. 2s + 7) as f16
+//   P2[piece][row][s]               4 bytes: the two features (row, 2s + 8), (row, 2s + 9)
+// and K is ordered to match: half-wave h takes kernel rows 5h .. 5h + 4; k-block kb < 5 = kernel row 5h + kb, taps kw 0..7 --
+// one aligned ds_read_b128 per piece; k-block 5 = taps kw 8, 9 of kernel rows 5h .. 5h + 3 (four dwords per piece), k-block 6 =
+// taps kw 8, 9 of kernel row 5h + 4 and six zeros.  (c1_pair is laid out in this order by kws_load_dscnn.)
+constexpr int C1W_ROWS = FEAT_H;                                   // 103 padded feature rows
+constexpr int OFF_C1W8 = OFF_Z1;                                   // floats; [2][103][3][4 dwords]
+constexpr int OFF_C1P2 = OFF_C1W8 + 2 * C1W_ROWS * 3 * 4;          // [2][103][3] dwords
+static_assert(OFF_C1P2 + 2 * C1W_ROWS * 3 <= OFF_Z0, "conv1's operand windows live where block 1's output goes later");
+static_assert(2 * (C1_W - 1) + 9 < FEAT_W && 2 * (C1_H - 1) + 9 < FEAT_H, "window reach inside the padded map");
+
+__device__ __forceinline__ void conv1_build_windows(float* lds, int tid, float sx) {
+    const float* featp = lds + OFF_FEAT;
+    uint32_t* w8 = reinterpret_cast<uint32_t*>(lds + OFF_C1W8);
+    uint32_t* p2 = reinterpret_cast<uint32_t*>(lds + OFF_C1P2);
+    for (int i = tid; i < C1W_ROWS * 3; i += NT) {
+        const float* src = featp + (i / 3) * FEAT_W + 2 * (i % 3);
+        const float y[8] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7]};
+        uintx4 hi, lo;
+        split_pair8(y, sx, hi, lo);
+        *reinterpret_cast<uintx4*>(w8 + i * 4) = hi;
+        *reinterpret_cast<uintx4*>(w8 + (C1W_ROWS * 3 + i) * 4) = lo;
+        uint32_t h, l;
+        split_pair2(src[8], src[9], sx, h, l);
+        p2[i] = h;
+        p2[C1W_ROWS * 3 + i] = l;
+    }
+}
+
+template <bool DUAL>
+__device__ __forceinline__ void conv1_unit_pairwin(const DscnnWeights& w, const float* lds, float* z0, int ptile, int ct, int lane,
+                                                   const uintx4 (&c1f)[7][2], int p_lo, int p_hi, float sig0, float& mx) {
+    const int half = lane >> 5, col = lane & 31;
+    const int pos = p_lo + ptile * 32 + col;
+    const int posc = pos < p_hi ? pos : p_hi - 1;
+    const int oh = posc / C1_W, ow = posc % C1_W;
+    const int wi = (2 * oh + 5 * half) * 3 + ow;  // window of kernel row 5h at this position; kernel row 5h + i: + 3i
+    const uintx4* w8 = reinterpret_cast<const uintx4*>(lds + OFF_C1W8) + wi;
+    const uint32_t* p2 = reinterpret_cast<const uint32_t*>(lds + OFF_C1P2) + wi;
+    const floatx16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 acc = zero, acc2 = zero, occ = zero, occ2 = zero;  // two chains per channel tile; occ*: the other channel tile (DUAL)
+    const uintx4* osrc = reinterpret_cast<const uintx4*>(w.c1_pair) + (size_t)(ct ^ 1) * (7 * 2 * 64) + lane;
+    // the other tile's A fragments, all seven k-blocks requested up front (L2 hits, but ~600 cycles away: with the operand split
+    // gone a k-block is too short to hide them two k-blocks ahead; the registers are free in this phase)
+    uintx4 of[DUAL ? 7 : 1][2];
+    if (DUAL) {
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb) {
+            of[kb][0] = osrc[(kb * 2 + 0) * 64];
+            of[kb][1] = osrc[(kb * 2 + 1) * 64];
+        }
+    }
+    // the biases of this lane's accumulator rows (rows 4q .. 4q+3 = channels 8q + 4 half + 0..3: one float4 each), requested
+    // now: read in the epilogue they were an L2 round trip at the end of every unit
+    float4 cb[4], ob[DUAL ? 4 : 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cb[q] = *reinterpret_cast<const float4*>(w.c1_b + ct * 32 + 8 * q + 4 * half);
+        if (DUAL) ob[DUAL ? q : 0] = *reinterpret_cast<const float4*>(w.c1_b + (ct ^ 1) * 32 + 8 * q + 4 * half);
+    }
+    uintx4 bq[3][2];  // [k-block mod 3][piece], fetched two k-blocks ahead
+    auto b_load = [&](int kb, uintx4 (&d)[2]) {
+        if (kb < 5) {
+            d[0] = w8[kb * 3];
+            d[1] = w8[kb * 3 + C1W_ROWS * 3];
+        } else if (kb == 5) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[0][i] = p2[i * 3];
+                d[1][i] = p2[i * 3 + C1W_ROWS * 3];
+            }
+        } else {
+            d[0] = uintx4{p2[4 * 3], 0u, 0u, 0u};
+            d[1] = uintx4{p2[4 * 3 + C1W_ROWS * 3], 0u, 0u, 0u};
+        }
+    };
+    b_load(0, bq[0]);
+    b_load(1, bq[1]);
+#pragma unroll
+    for (int kb = 0; kb < 7; ++kb) {
+        if (kb + 2 < 7) b_load(kb + 2, bq[(kb + 2) % 3]);
+        const uintx4 &bh = bq[kb % 3][0], &bl = bq[kb % 3][1];
+        // (hi, lo) (lo, hi) (hi, hi), the two channel tiles interleaved
+        acc2 = mfma_f16(c1f[kb][0], bl, acc2);
+        if (DUAL) occ2 = mfma_f16(of[DUAL ? kb : 0][0], bl, occ2);
+        acc = mfma_f16(c1f[kb][1], bh, acc);
+        if (DUAL) occ = mfma_f16(of[DUAL ? kb : 0][1], bh, occ);
+        acc2 = mfma_f16(c1f[kb][0], bh, acc2);
+        if (DUAL) occ2 = mfma_f16(of[DUAL ? kb : 0][0], bh, occ2);
+    }
+    acc += acc2;
+    occ += occ2;
+    if (pos < p_hi) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {  // accumulator rows r, r+1 are adjacent output channels: one 8-byte store
+            const int co = ct * 32 + row_of(r, half);
+            const float4 b4 = cb[r >> 2];
+            const float b0 = (r & 2) ? b4.z : b4.x, b1 = (r & 2) ? b4.w : b4.y;
+            const float v0 = relu(fmaf(b0, sig0, acc[r])), v1 = relu(fmaf(b1, sig0, acc[r + 1]));
+            *reinterpret_cast<float2*>(z0 + pidx(co, pos, P0 + 2)) = make_float2(v0, v1);
+            mx = fmaxf(mx, fmaxf(v0, v1));
+            if (DUAL) {
+                const int oo = (ct ^ 1) * 32 + row_of(r, half);
+                const float4 o4 = ob[DUAL ? (r >> 2) : 0];
+                const float c0 = (r & 2) ? o4.z : o4.x, c1 = (r & 2) ? o4.w : o4.y;
+                const float u0 = relu(fmaf(c0, sig0, occ[r])), u1 = relu(fmaf(c1, sig0, occ[r + 1]));
+                *reinterpret_cast<float2*>(z0 + pidx(oo, pos, P0 + 2)) = make_float2(u0, u1);
+                mx = fmaxf(mx, fmaxf(u0, u1));
+            }
+        }
+    }
+}
+
 // Rows [lo, hi) of a map, as flattened positions [lo * W, hi * W): what one workgroup of a time-tile cluster computes of a
 // stage (the streaming push at few streams, see kws_dscnn_fwd_kernel).  The full map when the workgroup owns the clip.
 struct PosRange {
@@ -483,7 +600,15 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
     float* z0 = lds + OFF_Z0;
     const int lane = tid & 63, wv = tid >> 6;
     float mx = 0.f;
-    if constexpr (RANGED) {
+    if constexpr (NP == 2) {  // f16 pairs: operands from the pre-split windows (built by the caller, behind a barrier)
+        if constexpr (RANGED) {
+            const int n_pt = (rg.hi - rg.lo + 31) / 32;
+            for (int u = wv; u < 2 * n_pt; u += NW) conv1_unit_pairwin<false>(w, lds, z0, u >> 1, u & 1, lane, c1f, rg.lo, rg.hi, sig0, mx);
+        } else if (wv < 4)
+            conv1_unit_pairwin<true>(w, lds, z0, wv, wv & 1, lane, c1f, 0, P0, sig0, mx);
+        else if (wv < 6)
+            conv1_unit_pairwin<false>(w, lds, z0, 4, wv & 1, lane, c1f, 0, P0, sig0, mx);
+    } else if constexpr (RANGED) {
         // a time tile holds at most 4 position tiles of 32: one (tile, channel tile) unit per wavefront, one round -- the
         // shortest critical path (a dual unit carries twice the matrix work); c1f holds channel tile wv & 1
         const int n_pt = (rg.hi - rg.lo + 31) / 32;
@@ -1249,6 +1374,8 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         ky[1] = pow2_exp_for(by1);
         cap_units(ky[1], sg[1], w.k_pw[0], (w.pw_abs[0] * by1 + w.pw_bmax[0]) * 1.001f);
         store_block_tables(lds, 1, tid, t1, pow2f(sg[0]), pow2f(sg[1]));  // (read in block 1, behind conv1's barrier)
+        conv1_build_windows(lds, tid, pow2f(kx));                          // conv1's operands, split once
+        __syncthreads();
     }
     stamp();  // 1: features staged
 
