@@ -45,7 +45,8 @@
 //   Z3 (block3 out, 51x7)  @ 0      .. 22976     Z2 (block2 out, 49x5) @ 22976 .. 38784
 //   Z1 (block1 out, 47x3)  @ 0      .. 9152      Z0 (conv1 out, 47x3)  @ 9152  .. 18304
 //   padded MFCC 103x14     @ 18304  .. 19746     (conv1 phase only)
-//   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled
+//   conv1 operand windows  @ 0      .. 3090      (f16 pairs, conv1 phase only: where Z1 goes afterwards; conv1_build_windows)
+//   misc                   @ 38784  .. 40960     2 x depthwise table, 2 x pointwise bias, pooled, per-wavefront stage maxima (f16 pairs)
 #include <type_traits>
 
 #include "kws_internal.h"
