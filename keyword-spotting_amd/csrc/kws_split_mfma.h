@@ -81,7 +81,8 @@ __device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_
         "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixlo_f16 %1, %2, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %1, %3, 1.0, 0"
+        "v_fma_mixhi_f16 %1, %3, 1.0, 0\n\t"
+        "s_nop 1"  // (rule R6, see split_pair8)
         : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1)
         : "v"(y0), "v"(y1), "s"(e));
     hi = h;
@@ -116,6 +117,10 @@ __device__ __forceinline__ void split_pair8(const float (&y)[8], float e, uintx4
         "v_fma_mixhi_f16 %5, %11, 1.0, 0\n\t"
         "v_fma_mixhi_f16 %6, %13, 1.0, 0\n\t"
         "v_fma_mixhi_f16 %7, %15, 1.0, 0"
+#ifndef KWS_X_NO_SPLIT_NOP  // (the switch exists for tests/test_isa_hazards.py: without the wait the lint must report rule R6)
+        "\n\ts_nop 1"  // a just-written VGPR needs two wait states before a matrix instruction reads it as an operand; the compiler
+                       // pads only one after an asm block
+#endif
         : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(t0), "=&v"(t1), "=&v"(t2),
           "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
         : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "s"(e));

@@ -42,6 +42,7 @@ BASE_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{os.path.join(RO
 CACHE = os.path.join(tempfile.gettempdir(), "kws_isa_lint")
 
 VALU_DPP_WAIT = 2
+VALU_MFMA_WAIT = 2          # VALU write -> MFMA A/B/C operand read of the same VGPR
 EXEC_DPP_WAIT = 5
 DOT_VALU_WAIT = 3
 VALU_SGPR_LANESEL_WAIT = 4
@@ -222,7 +223,13 @@ def lint_function(body, mfma_waits, default_mfma_wait):
                     if age < need:
                         findings.append((ins.line, "R1", f"`{ins.text}` reads {r[0]}{r[1]} {age} wait state(s) after `{mop}` (line {mline}) wrote it; needs {need}"))
         if is_mfma(op):
-            pass  # MFMA -> MFMA dependencies (srcC forwarding, srcA/B) are scheduled by the compiler; no asm block issues MFMAs
+            # R6: a VGPR written by a VALU instruction (possibly inside an asm block the compiler cannot see into) and read as an
+            # MFMA operand needs VALU_MFMA_WAIT wait states in between (cdna_hip_programming.md 5.7 item 2: `s_nop 1` after a
+            # just-written "v" operand; the compiler pads only one state after ;;#ASMEND).  MFMA -> MFMA dependencies (srcC
+            # forwarding) are scheduled by the compiler; no asm block issues MFMAs.
+            for r in src:
+                if r in valu_age and valu_age[r] < VALU_MFMA_WAIT:
+                    findings.append((ins.line, "R6", f"`{ins.text}` reads {r[0]}{r[1]} as a matrix operand {valu_age[r]} wait state(s) after a VALU wrote it; needs {VALU_MFMA_WAIT}"))
         if is_dpp(ins) or (op.startswith("v_permlane") and "swap" in op):
             # DPP source = src0 (first source operand); permlane swaps read both operands
             srcs = src if op.startswith("v_permlane") else (regs_of(ins.operands[1]) if len(ins.operands) > 1 else set())
