@@ -96,14 +96,17 @@ int kws_frontend_math(kws_ctx* ctx);
 
 /* Selective float64 refinement of KWS_FE_F32 -- what makes the default front end meet psf's float64 arithmetic
  * (kws/libs/audio_processor.py:270-278) to 1e-4 on EVERY frame.  The float32 kernel measures, per frame, the span
- * max - min of its 26 log mel energies; a frame over `log_span` (natural-log units of power; default 12.0 = 52 dB) goes
+ * max - min of its 26 log mel energies; a frame over `log_span` (natural-log units of power; default 11.5 = 50 dB) goes
  * onto a device worklist and a second launch recomputes exactly those rows in float64 (no host read-back; a batch with
  * nothing listed pays one empty launch).  Frames under the threshold keep the float32 kernel's bits.  Measured against
- * the float64 oracle: unflagged frames within 6e-5 on noise, tones, chirps, gated bursts and speech-like clips; white
- * noise lists ~0.2 % of its frames, a clean tone over a quiet floor all of them.  The streaming push redoes a flagged
- * frame in float64 inside the same launch.  log_span <= 0 switches the refinement off (the float32 kernel alone: up to
- * 6e-4 on such frames).  Takes effect from the next call; KWS_FE_F64 (always float64) is unaffected. */
-#define KWS_FE_REFINE_SPAN_DEFAULT 12.0f
+ * the float64 oracle on 1.19 M frames of noise, tones, chirps, gated bursts, mixtures and speech-like clips
+ * (tools/fe_precision_audit.py): every frame within 1e-4, the worst unflagged one 9.7e-5 -- a float32 transform leaves little
+ * room: at 12.0 (the first setting) one frame in 300 000 of the tone-like clips reached 1.2e-4.  White noise lists ~0.5 % of
+ * its frames, a clean tone over a quiet floor all of them; callers who want a margin rather than the bound use KWS_FE_F64.
+ * The streaming push redoes a flagged frame in float64 inside the same launch.  log_span <= 0 switches the refinement off
+ * (the float32 kernel alone: up to 2e-3 on such frames).  Takes effect from the next call; KWS_FE_F64 (always float64) is
+ * unaffected. */
+#define KWS_FE_REFINE_SPAN_DEFAULT 11.5f
 int kws_set_frontend_refine(kws_ctx* ctx, float log_span);
 /* Frames that went through the float32 front end since kws_create (*frames_total), how many of them the refinement
  * recomputed in float64 (*frames_refined), and the number the last completed batched call listed (*last_call_refined).

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(F64_MAX_WAVES * 64) void kws_mfcc_f64_kernel(Fronte
 // counted by the float32 kernel) into the running total (ctr[2..3], 64 bits), keeps it as "last call" (ctr[4]) and clears
 // the counters for the next launch.
 #ifndef KWS_X_REFINE_WAVES
-#define KWS_X_REFINE_WAVES 8
+// 12: 3 072 wavefronts on 256 CUs take the ~2 200 flagged pairs of a 4096-clip noise batch (span threshold 11.5) in one round
+// (8: a second round for some, 25.0 vs 20.5 us; 16 fits the LDS too but spills under the 128-register cap: 28.0 us)
+#define KWS_X_REFINE_WAVES 12
 #endif
 constexpr int REFINE_WAVES = KWS_X_REFINE_WAVES;  // wavefronts per workgroup of the refinement kernel
 template <typename T>

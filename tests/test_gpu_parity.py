@@ -137,6 +137,29 @@ def test_mfcc_diverse_clips_incl_level_steps(native, ctx, dev, e2e_golden):
     assert np.abs(got2 - want2).max() <= TOL
 
 
+def test_mfcc_audit_hard_clips_need_the_11p5_threshold(native, ctx, dev):
+    """The four clips of the 1.19 M-frame audit (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt) in which a frame
+    with a log-mel span between 11.5 and 12.0 missed 1e-4 under round 2's threshold of 12.0: every frame is within the
+    tolerance at the shipped threshold, and the named frames miss it again when the threshold is put back -- the fixture
+    pins the reason the default is 11.5."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_hard_clips.npz"))
+    clips, frames = d["clips"], d["frames"]
+    want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
+    assert native.FE_REFINE_SPAN_DEFAULT <= 11.5
+    got = gpu_mfcc(ctx, dev, clips)[:, 0]
+    err = np.abs(got - want).max(axis=2)
+    assert err.max() <= TOL, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
+    ctx.set_frontend_refine(12.0)
+    try:
+        old = gpu_mfcc(ctx, dev, clips)[:, 0]
+    finally:
+        ctx.set_frontend_refine(native.FE_REFINE_SPAN_DEFAULT)
+    err_old = np.abs(old - want).max(axis=2)
+    named = [(i, int(f)) for i, fr in enumerate(frames) for f in fr if f >= 0]
+    assert all(err_old[i, f] > TOL for i, f in named), [(i, f, float(err_old[i, f])) for i, f in named]
+    assert (err_old > TOL).sum() == len(named)
+
+
 @pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
 def test_mfcc_random_batch(ctx, dev, kind, seed):
     clips = synth_clips(96, seed, kind)

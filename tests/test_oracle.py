@@ -8,6 +8,7 @@
    vector covers (PARITY UNPINNED for mel/log/DCT/lifter/energy).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -268,3 +269,15 @@ def test_endpointer_known_answer():
     assert events == [(82, 1), (222, 2)]
     short = EnergyEndpointer(-10.0)
     assert not any(short.update(0.0 if 10 <= t < 40 else -36.0)[0] for t in range(200))  # 30 voiced hops never reach 80 % of 40
+
+
+def test_audit_fixture_frames_sit_between_the_old_and_the_new_refinement_threshold():
+    """tests/golden/audit_hard_clips.npz (make_audit_fixture.py): the named frames have a log-mel span in (11.5, 12.0] --
+    flagged for the float64 refinement at the shipped threshold, not at round 2's."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_hard_clips.npz"))
+    assert d["clips"].shape == (4, 16000) and d["clips"].dtype == np.int16
+    for c, fr in zip(d["clips"], d["frames"]):
+        feat, _ = o.fbank(o.fix_length(o.pcm16_to_float(c), 16000))
+        lm = np.log(feat)
+        span = lm.max(1) - lm.min(1)
+        assert all(11.5 < span[f] <= 12.0 for f in fr if f >= 0), span[fr]

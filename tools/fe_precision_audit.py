@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Diagnostics (GPU box): audit of the front end's contract -- every MFCC frame within 1e-4 of the float64 oracle -- on a few
+hundred thousand frames the tests never saw: uniform and Gaussian noise at random levels, speech-like clips with random
+parameters, sparse bursts in digital silence, tones and chirps, fades, and mixtures of the above.  Prints the worst error, the
+number of frames over 1e-4 (must be 0), how many frames the kernel refined in float64, and the error by log-mel span of the
+frames it did NOT refine (the margin of the span threshold).
+
+    python tools/fe_precision_audit.py [clips per generator = 400] [seed = 0] [span threshold = the library's default; 0 = refinement off]
+Test / diagnostic infrastructure: imports oracle/."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "keyword-spotting_amd")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from oracle import psf_mfcc as o
+from kws import _native
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+thr = float(sys.argv[3]) if len(sys.argv) > 3 else None
+import audit_clips
+sets = audit_clips.make_sets(N, seed)
+dev = torch.device("cuda", 0)
+ctx = _native.Context(0)
+if thr is not None:
+    ctx.set_frontend_refine(thr)
+print(f"front-end precision audit: {N} clips per generator, seed {seed}, refinement span threshold {_native.FE_REFINE_SPAN_DEFAULT if thr is None else thr}")
+worst_all, over_all, frames_all = 0.0, 0, 0
+span_bins = [(0, 8), (8, 9), (9, 9.5), (9.5, 10), (10, 10.25), (10.25, 10.5), (10.5, 10.75), (10.75, 11), (11, 11.25), (11.25, 11.5), (11.5, 11.75),
+             (11.75, 12.0), (12.0, 12.5), (12.5, 13), (13, 14), (14, 99)]
+by_span = {b: [0, 0.0] for b in span_bins}
+dump = []   # per frame: raw error, log-mel span, log of sum_j exp(2 (Lmax - L_j)), the largest |error| cepstrum index, generator id
+dump_path = os.environ.get("KWS_AUDIT_DUMP")
+for tag, clips in sets.items():
+    before = ctx.frontend_stats()
+    out = torch.empty((len(clips), 1, 99, 10), dtype=torch.float32, device=dev)
+    ctx.mfcc_i16(torch.from_numpy(np.ascontiguousarray(clips)).to(dev), out)
+    ctx.sync()
+    after = ctx.frontend_stats()
+    got = out.cpu().numpy()[:, 0].astype(np.float64)
+    t0 = time.perf_counter()
+    worst, over = 0.0, 0
+    for ci, c in enumerate(clips):
+        want = o.extract_features_pcm16(c)
+        err = np.abs(got[ci] - want).max(axis=1)
+        feat, _ = o.fbank(o.fix_length(o.pcm16_to_float(c), 16000))
+        lm = np.log(feat)
+        span = lm.max(1) - lm.min(1)
+        if dump_path:
+            lse = np.log(np.exp(2.0 * (lm.max(1, keepdims=True) - lm)).sum(1))
+            dump.append(np.stack([err, span, lse, np.abs(got[ci] - want).argmax(axis=1), np.full(99, list(sets).index(tag))], 1).astype(np.float32))
+        worst = max(worst, float(err.max()))
+        over += int((err > 1e-4).sum())
+        for b in span_bins:
+            m = (span > b[0]) & (span <= b[1])
+            if m.any():
+                by_span[b][0] += int(m.sum())
+                by_span[b][1] = max(by_span[b][1], float(err[m].max()))
+    n = len(clips) * 99
+    print(f"  {tag:10s} {n:7d} frames: worst |err| {worst:.2e}, over 1e-4: {over}, refined in float64: {after[1] - before[1]} ({100.0 * (after[1] - before[1]) / n:.2f} %)")
+    worst_all, over_all, frames_all = max(worst_all, worst), over_all + over, frames_all + n
+print(f"ALL: {frames_all} frames, worst |err| {worst_all:.2e}, frames over 1e-4: {over_all}")
+print("worst error by log-mel span of the frame (frames above the threshold were refined in float64):")
+for b in span_bins:
+    print(f"  span ({b[0]:4.1f}, {b[1]:4.1f}]: {by_span[b][0]:7d} frames, worst |err| {by_span[b][1]:.2e}")
+ctx.close()
+if dump_path:
+    np.save(dump_path, np.concatenate(dump))
+sys.exit(0 if over_all == 0 else 1)

@@ -7,7 +7,7 @@ from kws import _native
 e=np.load(ROOT+"/tests/golden/e2e_golden.npz"); g=np.load(ROOT+"/tests/golden/stress_golden.npz")
 clips=np.concatenate([e["clips"], g["speech_clips"]]); dev=torch.device("cuda",0)
 names=[str(n) for n in e["names"]]+[str(n) for n in g["speech_names"]]
-for span in (12.0, 0.0):
+for span in (_native.FE_REFINE_SPAN_DEFAULT, 0.0):
   for tag in ("he","he5","raw"):
     c=_native.Context(0); c.set_frontend_refine(span); c.load_dscnn(g[tag+".blob"],12)
     wav=torch.from_numpy(clips).to(dev); lo=torch.empty((len(clips),12),dtype=torch.float32,device=dev); la=torch.empty((len(clips),),dtype=torch.int32,device=dev)
