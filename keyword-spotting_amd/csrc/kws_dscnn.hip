@@ -178,19 +178,22 @@ __device__ __forceinline__ void fetch_block_tables(const DscnnWeights& w, int n,
     r.d1 = NT + tid < CH * 12 ? src[NT + tid] : 0.f;
     r.b = tid < CH ? w.pw_b[(n - 1) * CH + tid] : 0.f;
 }
-// s_dwb / s_pwb (f16-pair arithmetic; 1 otherwise): the block's activations are kept in LDS scaled by per-clip powers of two,
-// so its depthwise bias is stored in the units of its input and its pointwise bias (= accumulator seed and ring value) in the
-// units of its output.
-__device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r, float s_dwb = 1.f, float s_pwb = 1.f) {
+// s_dww / s_dwb / s_pwb (f16-pair arithmetic; 1 otherwise): the block's activations are kept in LDS scaled by per-clip powers
+// of two and its depthwise OUTPUT is wanted in the operand units 2^ky of the matrix instructions (below 2^15): the depthwise
+// weights carry the factor 2^(ky - input units), the depthwise bias 2^ky, so the stencil's result needs no scaling before it is
+// split (powers of two: the same bits as scaling afterwards); the pointwise bias (= accumulator seed and ring value) is stored
+// in the units of the block's output.
+__device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r, float s_dwb = 1.f, float s_pwb = 1.f,
+                                                   float s_dww = 1.f) {
     float* dwtab = lds + OFF_DWTAB + ((n - 1) & 1) * 768;
-    if (tid < CH * 12) dwtab[tid] = tid % 12 == 9 ? r.d0 * s_dwb : r.d0;
-    if (NT + tid < CH * 12) dwtab[NT + tid] = (NT + tid) % 12 == 9 ? r.d1 * s_dwb : r.d1;
+    if (tid < CH * 12) dwtab[tid] = r.d0 * (tid % 12 == 9 ? s_dwb : s_dww);
+    if (NT + tid < CH * 12) dwtab[NT + tid] = r.d1 * ((NT + tid) % 12 == 9 ? s_dwb : s_dww);
     if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b * s_pwb;
 }
 // f16-pair arithmetic: what a stage needs to know about the clip's scales (all powers of two)
 struct PairCtx {
-    float e = 1.f;          // the stage's operand scale: depthwise output (in the units its input is stored in) * e < 2^15
-    float s_dwb = 1.f;      // next block's depthwise bias factor = this block's output units
+    float s_dww = 1.f;      // next block's depthwise weight factor = its operand scale over this block's output units
+    float s_dwb = 1.f;      // next block's depthwise bias factor = its operand scale
     float s_pwb = 1.f;      // next block's pointwise bias factor = the next block's output units
     float inv_out = 1.f;    // block 4: pooled sums back to true units
 };
@@ -630,7 +633,7 @@ __device__ __forceinline__ void conv1_phase_split(const DscnnWeights& w, float* 
 // for both output-channel tiles.  Eight stencil steps, one split, twelve MFMAs, the raw partial sums (no bias, no ReLU) of the
 // tile's valid columns to part[M][cout][position in tile].  af: the pre-split weights of k-block M (requested long before).
 template <int N, int NP>
-__device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int M, const uintx4 (&af)[2][NP], float e) {
+__device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int M, const uintx4 (&af)[2][NP]) {
     using G = Blk<N>;
     using L = Leftover<N>;
     const int half = lane >> 5, col = lane & 31;
@@ -669,8 +672,7 @@ __device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int 
     floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
     if constexpr (NP == 2) {  // f16 pair: (hi,lo) (lo,hi) (hi,hi)
         uintx4 bh, bl;
-        split_pair8(y, e, bh, bl);
-        asm volatile("s_nop 1" : "+v"(bh), "+v"(bl));  // the split is an asm block: keep the matrix core off its last write
+        split_pair8_scaled(y, bh, bl);  // (ends with the two wait states a matrix operand needs)
         acc0 = mfma_f16(af[0][0], bl, acc0);
         acc1 = mfma_f16(af[1][0], bl, acc1);
         acc0 = mfma_f16(af[0][1], bh, acc0);
@@ -915,7 +917,8 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                     }
                     if (j == 7) {
                         if constexpr (PAIR) {
-                            split_pair8(y, pc.e, bh, bl);  // (the next product reads bl a stencil evaluation later)
+                            split_pair8_scaled(y, bh, bl);  // (the next product reads bl a stencil evaluation later; the operand
+                                                            // scale sits in the depthwise table: store_block_tables)
                         } else {
                             split3(y, bh, bm, bl);
                         }
@@ -1067,12 +1070,12 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     if constexpr (KSL) {
         using L = Leftover<N>;
         if (wv >= L::WAVE0 && wv < L::WAVE0 + 4) {
-            leftover_partial_unit<N, NP>(lds, lane, wv - L::WAVE0, pwo.ring[0], pc.e);
+            leftover_partial_unit<N, NP>(lds, lane, wv - L::WAVE0, pwo.ring[0]);
             __builtin_amdgcn_sched_barrier(0);
             load_afrag(w, N + 1, 0, lane, pwo.ring[0]);  // the next block's first operands fly across the barrier
         }
     }
-    if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables, pc.s_dwb, pc.s_pwb);
+    if constexpr (N < 4) store_block_tables(lds, N + 1, tid, next_tables, pc.s_dwb, pc.s_pwb, pc.s_dww);
     if constexpr (PAIR && N <= 2) publish_wave_max(lds, N == 1 ? 2 : 0, wv, lane, stage_max);
     if constexpr (MFMA) {
         if constexpr (N < 4) {
@@ -1374,7 +1377,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const float by1 = (w.dw_abs[0] * bz0 + w.dw_bmax[0]) * 1.001f;
         ky[1] = pow2_exp_for(by1);
         cap_units(ky[1], sg[1], w.k_pw[0], (w.pw_abs[0] * by1 + w.pw_bmax[0]) * 1.001f);
-        store_block_tables(lds, 1, tid, t1, pow2f(sg[0]), pow2f(sg[1]));  // (read in block 1, behind conv1's barrier)
+        store_block_tables(lds, 1, tid, t1, pow2f(ky[1]), pow2f(sg[1]), pow2f(ky[1] - sg[0]));  // (read in block 1, behind conv1's barrier)
         conv1_build_windows(lds, tid, pow2f(kx));                          // conv1's operands, split once
         __syncthreads();
     }
@@ -1408,7 +1411,7 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const float by1 = (w.dw_abs[0] * mz0 + w.dw_bmax[0]) * 1.001f;
         ky[1] = pow2_exp_for(by1);
         cap_units(ky[1], sg[1], w.k_pw[0], (w.pw_abs[0] * by1 + w.pw_bmax[0]) * 1.001f);
-        store_block_tables(lds, 1, tid, t1_pre, 1.f, pow2f(sg[1]));
+        store_block_tables(lds, 1, tid, t1_pre, pow2f(ky[1]), pow2f(sg[1]), pow2f(ky[1]));
         __syncthreads();
     }
     if constexpr (PAIR) {
@@ -1419,8 +1422,8 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const float by = (w.dw_abs[1] * bz + w.dw_bmax[1]) * 1.001f;
         ky[2] = pow2_exp_for(by);
         cap_units(ky[2], sg[2], w.k_pw[1], (w.pw_abs[1] * by + w.pw_bmax[1]) * 1.001f);
-        pc.e = pow2f(ky[1] - sg[0]);
-        pc.s_dwb = pow2f(sg[1]);
+        pc.s_dww = pow2f(ky[2] - sg[1]);
+        pc.s_dwb = pow2f(ky[2]);
         pc.s_pwb = pow2f(sg[2]);
     }
     block_phase<1, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg1, pc);
@@ -1444,8 +1447,8 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const float by = (w.dw_abs[2] * bz + w.dw_bmax[2]) * 1.001f;
         ky[3] = pow2_exp_for(by);
         cap_units(ky[3], sg[3], w.k_pw[2], (w.pw_abs[2] * by + w.pw_bmax[2]) * 1.001f);
-        pc.e = pow2f(ky[2] - sg[1]);
-        pc.s_dwb = pow2f(sg[2]);
+        pc.s_dww = pow2f(ky[3] - sg[2]);
+        pc.s_dwb = pow2f(ky[3]);
         pc.s_pwb = pow2f(sg[3]);
     }
     block_phase<2, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg2, pc);
@@ -1468,8 +1471,8 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         const float by = (w.dw_abs[3] * bz + w.dw_bmax[3]) * 1.001f;
         ky[4] = pow2_exp_for(by);
         cap_units(ky[4], sg[4], w.k_pw[3], (w.pw_abs[3] * by + w.pw_bmax[3]) * 1.001f);
-        pc.e = pow2f(ky[3] - sg[2]);
-        pc.s_dwb = pow2f(sg[3]);
+        pc.s_dww = pow2f(ky[4] - sg[3]);
+        pc.s_dwb = pow2f(ky[4]);
         pc.s_pwb = pow2f(sg[4]);
     }
     block_phase<3, MODE, CLUSTER>(w, lds, tid, wa, nullptr, rg3, pc);
@@ -1483,7 +1486,6 @@ __global__ __launch_bounds__(NT) void kws_dscnn_fwd_kernel(DscnnWeights w, const
         a += CH * Blk<3>::POUT;
     }
     if constexpr (PAIR) {
-        pc.e = pow2f(ky[4] - sg[3]);
         pc.inv_out = pow2f(-sg[4]);
     }
     block_phase<4, MODE, CLUSTER>(w, lds, tid, wa, a ? a + CH : nullptr, rg4, pc);  // block 4's output follows the pooled means

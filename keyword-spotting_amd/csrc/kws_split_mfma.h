@@ -76,12 +76,12 @@ __device__ __forceinline__ floatx16 mfma_f16(const uintx4& a, const uintx4& b, f
 __device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_t& hi, uint32_t& lo) {
     float t0, t1;
     uint32_t h, l;
-    asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
-        "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
-        "v_fma_mix_f32 %2, %4, %6, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %1, %2, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %1, %3, 1.0, 0\n\t"
+    asm("v_mul_f32 %2, %4, %6\n\t"
+        "v_mul_f32 %3, %5, %6\n\t"
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %1, %2, %3\n\t"
         "s_nop 1"  // (rule R6, see split_pair8)
         : "=&v"(h), "=&v"(l), "=&v"(t0), "=&v"(t1)
         : "v"(y0), "v"(y1), "s"(e));
@@ -90,40 +90,58 @@ __device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_
 }
 // Eight values at once, as ONE asm block (four separate blocks get an s_nop from the compiler between each other): the four
 // dwords' instructions are interleaved, so an instruction's source was written four instructions earlier.
+// v_cvt_pk_f16_f32 (gfx950) rounds two values in one full-rate instruction; v_fma_mixlo/mixhi_f16, which this used until late
+// in round 3, issue at the transcendental rate (tools/valu_rate.hip: 6.4 SIMD cycles each with two wavefronts on the SIMD
+// against 3.4 for v_cvt_pk_f16_f32 and v_fma_mix_f32, 2.3 for v_mul_f32): 72 instead of 129 SIMD cycles per eight values, same
+// bits (x * e is exact, both forms round to nearest even once).
+#define KWS_SPLIT8_TAIL                                                                                     \
+        "v_cvt_pk_f16_f32 %0, %8, %9\n\t"                                                                   \
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"                                                                 \
+        "v_cvt_pk_f16_f32 %2, %12, %13\n\t"                                                                 \
+        "v_cvt_pk_f16_f32 %3, %14, %15\n\t"                                                                 \
+        "v_fma_mix_f32 %8, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"                                              \
+        "v_fma_mix_f32 %10, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"                                            \
+        "v_fma_mix_f32 %12, %2, -1.0, %12 op_sel_hi:[1,0,0]\n\t"                                            \
+        "v_fma_mix_f32 %14, %3, -1.0, %14 op_sel_hi:[1,0,0]\n\t"                                            \
+        "v_fma_mix_f32 %9, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                               \
+        "v_fma_mix_f32 %11, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                             \
+        "v_fma_mix_f32 %13, %2, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                             \
+        "v_fma_mix_f32 %15, %3, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"                             \
+        "v_cvt_pk_f16_f32 %4, %8, %9\n\t"                                                                   \
+        "v_cvt_pk_f16_f32 %5, %10, %11\n\t"                                                                 \
+        "v_cvt_pk_f16_f32 %6, %12, %13\n\t"                                                                 \
+        "v_cvt_pk_f16_f32 %7, %14, %15"
+#ifndef KWS_X_NO_SPLIT_NOP  // (the switch exists for tests/test_isa_hazards.py: without the wait the lint must report rule R6)
+#define KWS_SPLIT8_NOP "\n\ts_nop 1"  // a just-written VGPR needs two wait states before a matrix instruction reads it as an
+                                      // operand; the compiler pads only one after an asm block
+#else
+#define KWS_SPLIT8_NOP ""
+#endif
 __device__ __forceinline__ void split_pair8(const float (&y)[8], float e, uintx4& hi, uintx4& lo) {
     uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
     float t0, t1, t2, t3, t4, t5, t6, t7;
-    asm("v_fma_mixlo_f16 %0, %16, %24, 0\n\t"
-        "v_fma_mixlo_f16 %1, %18, %24, 0\n\t"
-        "v_fma_mixlo_f16 %2, %20, %24, 0\n\t"
-        "v_fma_mixlo_f16 %3, %22, %24, 0\n\t"
-        "v_fma_mixhi_f16 %0, %17, %24, 0\n\t"
-        "v_fma_mixhi_f16 %1, %19, %24, 0\n\t"
-        "v_fma_mixhi_f16 %2, %21, %24, 0\n\t"
-        "v_fma_mixhi_f16 %3, %23, %24, 0\n\t"
-        "v_fma_mix_f32 %8, %16, %24, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %10, %18, %24, -%1 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %12, %20, %24, -%2 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %14, %22, %24, -%3 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %9, %17, %24, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %11, %19, %24, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %13, %21, %24, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %15, %23, %24, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %4, %8, 1.0, 0\n\t"
-        "v_fma_mixlo_f16 %5, %10, 1.0, 0\n\t"
-        "v_fma_mixlo_f16 %6, %12, 1.0, 0\n\t"
-        "v_fma_mixlo_f16 %7, %14, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %4, %9, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %5, %11, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %6, %13, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %7, %15, 1.0, 0"
-#ifndef KWS_X_NO_SPLIT_NOP  // (the switch exists for tests/test_isa_hazards.py: without the wait the lint must report rule R6)
-        "\n\ts_nop 1"  // a just-written VGPR needs two wait states before a matrix instruction reads it as an operand; the compiler
-                       // pads only one after an asm block
-#endif
+    asm("v_mul_f32 %8, %16, %24\n\t"
+        "v_mul_f32 %9, %17, %24\n\t"
+        "v_mul_f32 %10, %18, %24\n\t"
+        "v_mul_f32 %11, %19, %24\n\t"
+        "v_mul_f32 %12, %20, %24\n\t"
+        "v_mul_f32 %13, %21, %24\n\t"
+        "v_mul_f32 %14, %22, %24\n\t"
+        "v_mul_f32 %15, %23, %24\n\t"
+        KWS_SPLIT8_TAIL KWS_SPLIT8_NOP
         : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(t0), "=&v"(t1), "=&v"(t2),
           "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
         : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "s"(e));
+    hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3;
+    lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3;
+}
+// The same for values that arrive already scaled (the DS-CNN folds a block's operand scale into its depthwise table): the
+// residuals overwrite the values.
+__device__ __forceinline__ void split_pair8_scaled(float (&y)[8], uintx4& hi, uintx4& lo) {
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    asm(KWS_SPLIT8_TAIL KWS_SPLIT8_NOP
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]),
+          "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
     hi[0] = h0; hi[1] = h1; hi[2] = h2; hi[3] = h3;
     lo[0] = l0; lo[1] = l1; lo[2] = l2; lo[3] = l3;
 }
