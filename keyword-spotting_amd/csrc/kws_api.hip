@@ -570,9 +570,10 @@ int kws_load_dscnn_ex(kws_ctx* c, const float* blob, size_t n_floats, int num_cl
     src += 64;
     for (int b = 0; b < 4; ++b) {
         const float *dw_w = src, *dw_b = src + 576, *pw_w = src + 640, *pw_b = src + 640 + 4096;
-        for (int ch = 0; ch < 64; ++ch) {
-            for (int t = 0; t < 9; ++t) h[o_dw + ((size_t)b * 64 + ch) * 12 + t] = dw_w[ch * 9 + t];
-            h[o_dw + ((size_t)b * 64 + ch) * 12 + 9] = dw_b[ch];
+        for (int ch = 0; ch < 64; ++ch) {  // channel PAIRS interleaved, 24 floats per pair: (tap t of ch, of ch + 1) at 2t, the biases at 18, 19
+            float* q = &h[o_dw + ((size_t)b * 32 + ch / 2) * 24 + (ch & 1)];
+            for (int t = 0; t < 9; ++t) q[2 * t] = dw_w[ch * 9 + t];
+            q[18] = dw_b[ch];
         }
         for (int co = 0; co < 64; ++co)  // pointwise.weight [cout][cin][1][1] -> [cin][cout]
             for (int ci = 0; ci < 64; ++ci) h[o_pww + (size_t)b * 4096 + (size_t)ci * 64 + co] = pw_w[co * 64 + ci];

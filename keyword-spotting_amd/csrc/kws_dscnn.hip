@@ -154,6 +154,21 @@ __device__ __forceinline__ float stencil3x3(float w0, float w1, float w2, float 
     if constexpr (TO_MFMA) asm volatile("s_nop 1" : "+v"(c));
     return c;
 }
+// The depthwise table is interleaved in channel PAIRS: ten (channel c, channel c + 1) pairs -- nine taps and the bias -- are 80
+// bytes, FIVE ds_read_b128 for two stencil steps where a table per channel took six.  (A wavefront's issue slots are what
+// this kernel is made of; `tools/experiments/dscnn_unit_ablations.patch`: without the weight reloads it runs 9.5 % faster.)
+struct DwPair {
+    float4 l[5];  // (w0, w1) (w2, w3) (w4, w5) (w6, w7) (w8, b), each a (channel c, channel c + 1) pair
+};
+template <bool TO_MFMA, int E>  // E: which channel of the pair
+__device__ __forceinline__ float stencil3x3_of_pair(const DwPair& w, float up, float mid, float dn, float mask_l, float mask_r) {
+    if constexpr (E == 0)
+        return stencil3x3<TO_MFMA>(w.l[0].x, w.l[0].z, w.l[1].x, w.l[1].z, w.l[2].x, w.l[2].z, w.l[3].x, w.l[3].z, w.l[4].x, w.l[4].z, up, mid, dn,
+                                   mask_l, mask_r);
+    else
+        return stencil3x3<TO_MFMA>(w.l[0].y, w.l[0].w, w.l[1].y, w.l[1].w, w.l[2].y, w.l[2].w, w.l[3].y, w.l[3].w, w.l[4].y, w.l[4].w, up, mid, dn,
+                                   mask_l, mask_r);
+}
 // Sum over each 32-lane half of the wavefront without touching LDS: inclusive scan inside the 16-lane rows
 // (row_shr 1,2,4,8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15).  Lanes 31 and 63 hold the totals.
 // (dpp_shift_add<CTRL, ROW_MASK>: kws_mfcc_dev.h)
@@ -166,7 +181,7 @@ __device__ __forceinline__ float half_wave_sum_to_last_lane(float v) {
     return v;
 }
 
-// Depthwise table [64][12] and pointwise bias [64] of block n (1..4) go to LDS buffer (n-1)&1 in two
+// Depthwise table [32 channel pairs][24] and pointwise bias [64] of block n (1..4) go to LDS buffer (n-1)&1 in two
 // halves so the global-memory latency hides under a whole phase: fetch() issues the loads into three
 // registers at the start of the previous phase, store() writes them to LDS after that phase's units.
 struct BlockTables {
@@ -186,8 +201,8 @@ __device__ __forceinline__ void fetch_block_tables(const DscnnWeights& w, int n,
 __device__ __forceinline__ void store_block_tables(float* lds, int n, int tid, const BlockTables& r, float s_dwb = 1.f, float s_pwb = 1.f,
                                                    float s_dww = 1.f) {
     float* dwtab = lds + OFF_DWTAB + ((n - 1) & 1) * 768;
-    if (tid < CH * 12) dwtab[tid] = r.d0 * (tid % 12 == 9 ? s_dwb : s_dww);
-    if (NT + tid < CH * 12) dwtab[NT + tid] = r.d1 * ((NT + tid) % 12 == 9 ? s_dwb : s_dww);
+    if (tid < CH * 12) dwtab[tid] = r.d0 * ((tid % 24) >> 1 == 9 ? s_dwb : s_dww);  // (pair-interleaved rows of 24: the biases at 18, 19)
+    if (NT + tid < CH * 12) dwtab[NT + tid] = r.d1 * (((NT + tid) % 24) >> 1 == 9 ? s_dwb : s_dww);
     if (tid < CH) lds[OFF_PWB + ((n - 1) & 1) * 64 + tid] = r.b * s_pwb;
 }
 // f16-pair arithmetic: what a stage needs to know about the clip's scales (all powers of two)
@@ -662,12 +677,11 @@ __device__ __forceinline__ void leftover_partial_unit(float* lds, int lane, int 
         const float2 up = *reinterpret_cast<const float2*>(lds + ta[0] + o);
         const float2 mid = *reinterpret_cast<const float2*>(lds + ta[1] + o);
         const float2 dn = *reinterpret_cast<const float2*>(lds + ta[2] + o);
+        DwPair wp;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float4 q0 = dwt4[(cs + e) * 3 + 0], q1 = dwt4[(cs + e) * 3 + 1], q2 = dwt4[(cs + e) * 3 + 2];
-            y[j + e] = stencil3x3<false>(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, e ? up.y : up.x, e ? mid.y : mid.x,
-                                         e ? dn.y : dn.x, mask_l, mask_r);
-        }
+        for (int i = 0; i < 5; ++i) wp.l[i] = dwt4[(cs >> 1) * 6 + i];
+        y[j] = stencil3x3_of_pair<false, 0>(wp, up.x, mid.x, dn.x, mask_l, mask_r);
+        y[j + 1] = stencil3x3_of_pair<false, 1>(wp, up.y, mid.y, dn.y, mask_l, mask_r);
     }
     floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
     if constexpr (NP == 2) {  // f16 pair: (hi,lo) (lo,hi) (hi,hi)
@@ -772,7 +786,7 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
     // accumulator rows 4q..4q+3 of tile ct are output channels ct*32 + 8q + 4*half + (0..3): one float4
     const float4* bias4 = reinterpret_cast<const float4*>(pwb) + half;
     // lane (column, half) walks the input channels 16m + 8*half + j (m = 0..3, j = 0..7) in 32 steps s = 8m + j
-    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;
+    const float4* dwt4 = reinterpret_cast<const float4*>(dwtab) + half * 24;  // (channel pair 4 * half; six float4 per pair, five of them read)
     float psum[2][16];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -806,10 +820,6 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             asm volatile("" : "+v"(thi[dh + 1]));
         }
 
-        struct Taps {
-            float4 q0, q1, q2;  // depthwise weights w0..w8, bias at q2.y
-            float up, mid, dn;  // input at rows h-1, h, h+1 of this lane's column
-        };
         auto cs_of = [](int s) { return 16 * (s >> 3) + (s & 7); };  // channel of step s minus the half's offset 8*half
         // the own-column inputs of channels (cs, cs+1), cs even, in three 8-byte reads (pair-interleaved planes)
         struct TapPair {
@@ -825,21 +835,16 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             }
             tp.mid = *reinterpret_cast<const float2*>(lds + ta[1] + o);
         };
-        auto take = [](Taps& tp, const TapPair& tq, int odd) {  // step 2sp + odd of the pair
-            tp.up = odd ? tq.up.y : tq.up.x;
-            tp.mid = odd ? tq.mid.y : tq.mid.x;
-            tp.dn = odd ? tq.dn.y : tq.dn.x;
+        // the depthwise weights of the step pair's two channels: five 16-byte reads (DwPair)
+        auto wts_pair_load = [&](int sp, DwPair& wp) {
+            const int cs = cs_of(2 * sp);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wp.l[i] = dwt4[(cs >> 1) * 6 + i];
         };
-        auto wts_load = [&](int s, Taps& tp) {
-            const int cs = cs_of(s);
-            tp.q0 = dwt4[cs * 3 + 0];
-            tp.q1 = dwt4[cs * 3 + 1];
-            tp.q2 = dwt4[cs * 3 + 2];
-        };
-        // depthwise 3x3 (+bias) of this step's channel at this lane's column -> one MFMA B operand element
-        auto dw_eval = [&](const Taps& tp) -> float {
-            return stencil3x3<(MFMA && !SPLIT)>(tp.q0.x, tp.q0.y, tp.q0.z, tp.q0.w, tp.q1.x, tp.q1.y, tp.q1.z, tp.q1.w, tp.q2.x,
-                                                tp.q2.y, tp.up, tp.mid, tp.dn, mask_l, mask_r);
+        // depthwise 3x3 (+bias) of step 2sp + odd at this lane's column -> one MFMA B operand element
+        auto dw_eval = [&](const DwPair& wp, const TapPair& tq, auto odd) -> float {
+            constexpr int E = decltype(odd)::value;
+            return stencil3x3_of_pair<(MFMA && !SPLIT), E>(wp, E ? tq.up.y : tq.up.x, E ? tq.mid.y : tq.mid.x, E ? tq.dn.y : tq.dn.x, mask_l, mask_r);
         };
 
         if constexpr (MFMA) {
@@ -851,11 +856,11 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
                 acc1[4 * q + 0] = b1.x; acc1[4 * q + 1] = b1.y; acc1[4 * q + 2] = b1.z; acc1[4 * q + 3] = b1.w;
             }
             // software pipeline, two steps deep: reads of step s+2 are issued before step s is evaluated
-            Taps ta0, ta1;
+            DwPair wq0, wq1;   // depthwise weights of step pairs, two pairs in flight
             TapPair tq0, tq1;  // inputs of step pairs, two pairs in flight
             if constexpr (!NO_STENCIL) {
-                wts_load(0, ta0);
-                wts_load(1, ta1);
+                wts_pair_load(0, wq0);
+                wts_pair_load(1, wq1);
             }
             tap_pair_load(0, tq0);
             tap_pair_load(1, tq1);
@@ -889,18 +894,20 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 #pragma unroll
                 for (int s = 0; s < 32; ++s) {
                     const int m = s >> 3, j = s & 7;
-                    Taps& tp = (s & 1) ? ta1 : ta0;
+                    DwPair& wp = (s & 2) ? wq1 : wq0;
                     TapPair& tq = (s & 2) ? tq1 : tq0;  // step pair s >> 1
                     const bool feed = m > 0 && j < NPROD;
                     if (feed) product(0, m - 1, j);
-                    take(tp, tq, s & 1);
-                    y[j] = NO_STENCIL ? tp.mid : dw_eval(tp);
+                    if constexpr (NO_STENCIL)
+                        y[j] = (s & 1) ? tq.mid.y : tq.mid.x;
+                    else
+                        y[j] = (s & 1) ? dw_eval(wp, tq, std::integral_constant<int, 1>{}) : dw_eval(wp, tq, std::integral_constant<int, 0>{});
                     __builtin_amdgcn_sched_barrier(0);
                     if (feed) product(1, m - 1, j);
-                    if constexpr (!NO_STENCIL) {
-                        if (s + 2 < 32) wts_load(s + 2, tp);
+                    if ((s & 1) && s + 3 < 32) {  // both steps of the pair are done: its registers take the pair after the next
+                        if constexpr (!NO_STENCIL) wts_pair_load((s >> 1) + 2, wp);
+                        tap_pair_load((s >> 1) + 2, tq);
                     }
-                    if ((s & 1) && s + 3 < 32) tap_pair_load((s >> 1) + 2, tq);  // both steps of the pair are done
                     __builtin_amdgcn_sched_barrier(0);
                     if (j == 6) {
                         // the products of k-block m-1 are done: its ring slot takes k-block m+1, or k-block 0 of
@@ -935,20 +942,18 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
 #pragma unroll
                 for (int s = 0; s < 32; s += 2) {  // one pair of k-steps per iteration
                     TapPair& tq = (s & 2) ? tq1 : tq0;
-                    take(ta0, tq, 0);
-                    take(ta1, tq, 1);
+                    DwPair& wp = (s & 2) ? wq1 : wq0;
                     float y0, y1;
                     if constexpr (MODE == 2) {  // timing ablation: matrix core only (results are wrong)
-                        y0 = ta0.mid;
-                        y1 = ta1.mid;
+                        y0 = tq.mid.x;
+                        y1 = tq.mid.y;
                     } else {
-                        y0 = dw_eval(ta0);
-                        y1 = dw_eval(ta1);
-                        if (s + 2 < 32) {
-                            wts_load(s + 2, ta0);
-                            wts_load(s + 3, ta1);
+                        y0 = dw_eval(wp, tq, std::integral_constant<int, 0>{});
+                        y1 = dw_eval(wp, tq, std::integral_constant<int, 1>{});
+                        if (s + 4 < 32) {
+                            wts_pair_load((s >> 1) + 2, wp);
+                            tap_pair_load((s >> 1) + 2, tq);
                         }
-                        if (s + 4 < 32) tap_pair_load((s >> 1) + 2, tq);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (MODE == 3) {  // timing ablation: stencil only (results are wrong)
@@ -1039,13 +1044,10 @@ __device__ __forceinline__ void block_phase(const DscnnWeights& w, float* lds, i
             for (int s = 0; s < 32; s += 2) {
                 TapPair tq;
                 tap_pair_load(s >> 1, tq);
-                Taps tp;
-                wts_load(s, tp);
-                take(tp, tq, 0);
-                y[s] = dw_eval(tp);
-                wts_load(s + 1, tp);
-                take(tp, tq, 1);
-                y[s + 1] = dw_eval(tp);
+                DwPair wp;
+                wts_pair_load(s >> 1, wp);
+                y[s] = dw_eval(wp, tq, std::integral_constant<int, 0>{});
+                y[s + 1] = dw_eval(wp, tq, std::integral_constant<int, 1>{});
             }
 #pragma unroll 1
             for (int co = 0; co < CH; ++co) {

@@ -139,7 +139,7 @@ constexpr int MAX_CLASSES = 64;
 struct DscnnWeights {
     const float* c1_w;     // [100][64]   conv1 weight transposed: [kh*10+kw][cout]
     const float* c1_b;     // [64]
-    const float* dw_w;     // [4][64][12] depthwise 3x3 taps [0..8], bias at [9], 2 pad
+    const float* dw_w;     // [4][32][24] depthwise 3x3, channel pairs interleaved: (tap t of channel 2p, of 2p + 1) at 2t, t = 0..8; the biases at 18, 19; 4 pad
     const float* pw_w;     // [4][64][64] pointwise transposed: [cin][cout]
     const float* pw_b;     // [4][64]
     const uint32_t* pw_split;  // [4][ct 2][m 4][piece 3][lane 64][4]  pointwise weights as bf16 hi/mid/lo MFMA A operands
