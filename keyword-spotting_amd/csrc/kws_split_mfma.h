@@ -70,9 +70,9 @@ typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx16 mfma_f16(const uintx4& a, const uintx4& b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b), c, 0, 0, 0);
 }
-// (y0, y1) * e -> one dword of hi pieces and one of PLAIN lo pieces; e is wavefront-uniform (a scalar register).  Six
-// full-rate VALU instructions for two values: v_fma_mixlo/hi_f16 convert with the scale folded in and write the two halves
-// of a dword in place, v_fma_mix_f32 forms y e - hi with the f16 piece read as an operand.
+// (y0, y1) * e -> one dword of hi pieces and one of PLAIN lo pieces; e is wavefront-uniform (a scalar register).  Six VALU
+// instructions for two values: two multiplies by e (exact), v_cvt_pk_f16_f32 rounds both to the hi dword, v_fma_mix_f32 forms
+// y e - hi with the f16 piece read as an operand, a second v_cvt_pk_f16_f32 packs the residuals (see split_pair8).
 __device__ __forceinline__ void split_pair2(float y0, float y1, float e, uint32_t& hi, uint32_t& lo) {
     float t0, t1;
     uint32_t h, l;
