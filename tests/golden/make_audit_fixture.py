@@ -22,3 +22,16 @@ for seed in (1, 2, 3):
             clips.append(sets[g][i]); names.append(f"seed{s}_{g}_{i}"); frames.append(list(fr) + [-1] * (2 - len(fr)))
 np.savez_compressed(os.path.join(HERE, "audit_hard_clips.npz"), clips=np.stack(clips), names=np.array(names), frames=np.array(frames, dtype=np.int32))
 print(names, np.stack(clips).shape)
+
+# The four frames of seeds 4..11 (2.38 M frames, audited after the threshold had been set) that miss 1e-4 AT the shipped threshold:
+# spans 10.8-11.5, float32 errors 1.2e-4 .. 1.5e-4 (profiles/r03_precision_audit.txt).  Kept as the documented exceptions of the
+# default front end: the test holds them under 2e-4 and holds KWS_FE_F64 to 1e-4 on them.
+EXCEPTIONS = [(4, "mix", 130, 97), (5, "tones", 54, 1), (11, "tones", 362, 56), (11, "mix", 125, 85)]
+clips, names, frames = [], [], []
+for seed in (4, 5, 11):
+    sets = audit_clips.make_sets(500, seed)
+    for s, g, i, f in EXCEPTIONS:
+        if s == seed:
+            clips.append(sets[g][i]); names.append(f"seed{s}_{g}_{i}"); frames.append(f)
+np.savez_compressed(os.path.join(HERE, "audit_exception_clips.npz"), clips=np.stack(clips), names=np.array(names), frames=np.array(frames, dtype=np.int32))
+print(names, np.stack(clips).shape)

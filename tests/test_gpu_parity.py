@@ -160,6 +160,28 @@ def test_mfcc_audit_hard_clips_need_the_11p5_threshold(native, ctx, dev):
     assert (err_old > TOL).sum() == len(named)
 
 
+def test_mfcc_documented_exceptions_stay_small_and_float64_has_none(native, dev):
+    """The four frames (of 2.38 M audited after the threshold had been set; profiles/r03_precision_audit.txt) on which the default
+    front end misses 1e-4: tone / chirp mixtures, log-mel spans 10.8-11.5 (under the refinement threshold), float32 errors
+    1.2e-4 .. 1.5e-4.  include/kws_hip.h names them as the exceptions of KWS_FE_F32's contract; this test pins their size, that
+    they are confined to the named frames, and that KWS_FE_F64 -- the strict setting -- meets the bound on all of them."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_exception_clips.npz"))
+    clips, frames = d["clips"], d["frames"]
+    want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
+    c = native.Context(0)
+    try:
+        got = gpu_mfcc(c, dev, clips)[:, 0]
+        err = np.abs(got - want).max(axis=2)
+        assert err.max() <= 2 * TOL, float(err.max())
+        over = np.argwhere(err > TOL)
+        assert {(int(i), int(f)) for i, f in over} <= {(i, int(f)) for i, f in enumerate(frames)}, over
+        c.set_frontend_math(native.FE_F64)
+        strict = gpu_mfcc(c, dev, clips)[:, 0]
+        assert np.abs(strict - want).max() <= TOL
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])
 def test_mfcc_random_batch(ctx, dev, kind, seed):
     clips = synth_clips(96, seed, kind)
