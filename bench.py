@@ -416,12 +416,12 @@ def refine_report(_native, ctx, B, steps_frames_before, steps):
     """What the selective float64 refinement of the float32 front end did during the timed steps."""
     total, refined, last = ctx.frontend_stats()
     r_ms, r_n = ctx.prof_read(_native.KWS_K_MFCC_REFINE)
-    return {"kernel": _native.kernel_name(_native.KWS_K_MFCC_REFINE), "log_span_threshold": _native.FE_REFINE_SPAN_DEFAULT,
+    return {"kernel": _native.kernel_name(_native.KWS_K_MFCC_REFINE), "log_peak_to_weakest_band_threshold": _native.FE_REFINE_SPAN_DEFAULT,
             "frames_per_step": B * 99, "frames_recomputed_per_step": last,
             "frames_recomputed_frac": (refined - steps_frames_before[1]) / max(total - steps_frames_before[0], 1),
             "avg_kernel_ms": r_ms / max(r_n, 1), "launches_timed": r_n,
-            "note": "frames whose 26 log-mel values span more than the threshold are listed by the float32 kernel and recomputed in "
-                    "float64 by this launch (one per MFCC call, empty lists included)"}
+            "note": "frames whose weakest mel band lies more than the threshold (natural log of power) below their largest spectral bin are "
+                    "listed by the float32 kernel and recomputed in float64 by this launch (one per MFCC call, empty lists included)"}
 
 
 def leg_mfcc_only(args, _native, torch, dev, B, cpu_n, precise=False):

@@ -95,24 +95,21 @@ int kws_set_frontend_math(kws_ctx* ctx, int math);
 int kws_frontend_math(kws_ctx* ctx);
 
 /* Selective float64 refinement of KWS_FE_F32 -- what makes the default front end meet psf's float64 arithmetic
- * (kws/libs/audio_processor.py:270-278) to 1e-4 frame by frame (on every frame of every test set and of 3.6 M audited
- * frames of noise, bursts and speech-like signals; on all but about two frames per million of adversarial tone / chirp
- * mixtures, where the misses reach 1.5e-4 -- see below; KWS_FE_F64 is the strict setting).  The float32 kernel measures, per frame, the span
- * max - min of its 26 log mel energies; a frame over `log_span` (natural-log units of power; default 11.5 = 50 dB) goes
- * onto a device worklist and a second launch recomputes exactly those rows in float64 (no host read-back; a batch with
- * nothing listed pays one empty launch).  Frames under the threshold keep the float32 kernel's bits.  Measured against
- * the float64 oracle on 3.56 M frames of noise, tones, chirps, gated bursts, mixtures and speech-like clips
- * (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt): the threshold was set on the first 1.19 M (every frame
- * within 1e-4, the worst unflagged one 9.7e-5; at 12.0, the first setting, six frames reached 1.0-1.2e-4); the 2.38 M
- * audited afterwards hold FOUR frames between 1.2e-4 and 1.5e-4, all tone-like, with spans of 10.8-11.5 -- worst-case
- * alignments of one weak band's float32 error that no cheap function of the mel envelope predicts (a threshold that
- * excluded them would list a quarter of all frames).  White noise lists ~0.5 % of its frames, a clean tone over a quiet
- * floor all of them; callers who need the bound without exception use KWS_FE_F64.
- * The streaming push redoes a flagged frame in float64 inside the same launch.  log_span <= 0 switches the refinement off
- * (the float32 kernel alone: up to 2e-3 on such frames).  Takes effect from the next call; KWS_FE_F64 (always float64) is
- * unaffected. */
-#define KWS_FE_REFINE_SPAN_DEFAULT 11.5f
-int kws_set_frontend_refine(kws_ctx* ctx, float log_span);
+ * (kws/libs/audio_processor.py:270-278) to 1e-4 on every frame.  A float32 transform leaves rounding noise a fixed distance
+ * below the frame's strongest spectral component, so the float32 kernel measures, per frame, how far its weakest mel band
+ * lies below its largest spectral bin: r = log(max bin power) - min log(mel energy) (natural-log units of power).  A frame
+ * with r over `log_ratio` (default 10.2 = 44 dB) goes onto a device worklist and a second launch recomputes exactly those
+ * rows in float64 (no host read-back; a batch with nothing listed pays one empty launch).  Frames under the threshold keep
+ * the float32 kernel's bits.  Measured against the float64 oracle on 3.56 M frames of noise, tones, chirps, gated bursts,
+ * mixtures and speech-like clips (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt): unflagged frames with
+ * r <= 10.2 stay within 7.3e-5 (one burst-onset frame in 3.56 M at 9.4e-5).  White noise lists ~0.3 % of its frames,
+ * speech-like clips ~5 %, a clean tone over a quiet floor all of them.  (Until late in round 3 the flag was the span max - min
+ * of the log-mel values with a threshold of 11.5: it cannot tell white noise, whose peak bin lies well below its strongest
+ * band, from a tone, and left four frames of 2.4 M at 1.2-1.5e-4.)  The streaming push redoes a flagged frame in float64
+ * inside the same launch.  log_ratio <= 0 switches the refinement off (the float32 kernel alone: up to 2e-3 on such
+ * frames).  Takes effect from the next call; KWS_FE_F64 (always float64) is unaffected.  The macro keeps its round-3 name. */
+#define KWS_FE_REFINE_SPAN_DEFAULT 10.2f
+int kws_set_frontend_refine(kws_ctx* ctx, float log_ratio);
 /* Frames that went through the float32 front end since kws_create (*frames_total), how many of them the refinement
  * recomputed in float64 (*frames_refined), and the number the last completed batched call listed (*last_call_refined).
  * Synchronises the context's stream.  Any pointer may be NULL. */

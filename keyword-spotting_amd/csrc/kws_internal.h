@@ -44,7 +44,7 @@ struct FrontendParams {
     int vec_ok;            // 1 -> every workgroup's first sample is 16-byte aligned (vector PCM loads legal)
     int nfft;              // transform length (the float32 kernel is built for 512; the float64 kernel takes any)
     int log2_nfft;         // log2(nfft) when nfft is a power of two, else 0 (float64 kernel: FFT vs direct DFT)
-    float refine_span;     // float32 kernels: a frame whose log-mel values span more than this is redone in float64 (0: never)
+    float refine_span;     // float32 kernels: a frame whose weakest mel band lies more than this (log power) below its largest bin is redone in float64 (0: never)
 };
 
 // Worklist of the selective float64 refinement: the float32 MFCC kernel appends, per frame pair with a

@@ -291,7 +291,7 @@ __device__ __forceinline__ void fill_tw2(const float2* __restrict__ tw, cf* tw2,
 // lv: the exact power-of-two factors that undo equalise_levels (applied to the powers before any square root).
 __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* pbuf, int lane, int power, bool nza,
                                             bool nzb, const int (&pslot)[4], int slot256, const PairLevel& lv, float& ea,
-                                            float& eb) {
+                                            float& eb, float* pk_a = nullptr, float* pk_b = nullptr) {
     const int k1 = lane >> 3, q = lane & 7;
 #pragma unroll
     for (int d = 0; d < 8; ++d) zbuf[zswz(k1 + 8 * q + 64 * d)] = v[d];
@@ -346,6 +346,23 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         if (slot256 >= 0) pbuf[slot256] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
+        if (pk_a) {  // (bin 256 joins this lane's peak below)
+            *pk_a = pa;
+            *pk_b = pb;
+        }
+    } else if (pk_a) {
+        *pk_a = 0.f;
+        *pk_b = 0.f;
+    }
+    if (pk_a) {  // this lane's largest bin power per frame: the precision flag measures the weakest mel band against the frame's peak
+        // (two v_max3_f32 per frame; fmaxf costs a canonicalising v_max per operand on top of the maximum itself)
+        float ta, tb, ka = *pk_a, kb = *pk_b;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(pb[0]), "v"(pb[1]), "v"(pb[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ka) : "v"(ta), "v"(pa[3]), "v"(ka));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(kb) : "v"(tb), "v"(pb[3]), "v"(kb));
+        *pk_a = ka;
+        *pk_b = kb;
     }
     wave_lds_order();
 }
@@ -430,22 +447,68 @@ __device__ __forceinline__ void segment_suffix_sums(float& a, float& b, float& c
             : "v"(m.m4));
 }
 
-// Precision flag of the float32 front end.  A float32 transform leaves rounding noise ~138 dB below a
-// frame's strongest component, so a mel band far below the strongest one carries a large relative error, which log, DCT and
-// lifter turn into a cepstral error: measured against the float64 reference, every frame whose log-mel values span less
-// than 12 (52 dB) stays within 6e-5, while a clean tone over a quiet floor (span 19) misses by up to 6e-4.  The span is
-// therefore taken here, from the log-mel values the lanes hold anyway, and frames over the threshold are redone in
-// float64 by the refinement kernel (batched) or on the spot (streaming).
-// v: the frame's centred log-mel value in lanes of the frame, 0 (= filter 0's value) in the others.  FULL = false: two
-// frames, one per 32-lane half -- the result is valid in lanes 31 and 63; FULL = true: one frame over 64 lanes, lane 63.
-// Returns the ballot of (max - min > thr).  Running maximum and minimum by DPP row scans; a lane without a source keeps
-// its value (no bound_ctrl: zeros shifted in would win a maximum of negative logs); the two chains alternate and one
-// s_nop separates a write from the DPP read of the same register (VALU -> DPP: two wait states, hidden from the compiler).
+// Two sums and two maxima (of non-negative values) over the wavefront at once: four chains alternate, so a register is read by
+// DPP three instructions after it was written and no s_nop is owed -- the two maxima ride in the slots wave_sum2 pads.
+__device__ __forceinline__ void wave_sum2_max2(float& a, float& b, float& ma, float& mb) {
+#define KWS_DPP_STEP(ctrl)                                                      \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n\t"                                      \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n\t"                                      \
+    "v_max_f32_dpp %2, %2, %2 " ctrl "\n\t"                                      \
+    "v_max_f32_dpp %3, %3, %3 " ctrl "\n\t"
+    asm("s_nop 1\n\t"
+        KWS_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        KWS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        KWS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 0"  // (the last write of %3 and whatever reads it next)
+        : "+v"(a), "+v"(b), "+v"(ma), "+v"(mb));
+#undef KWS_DPP_STEP
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+    ma = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ma), 63));
+    mb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mb), 63));
+}
+
+// Precision flag of the float32 front end.  A float32 transform leaves rounding noise a fixed distance below
+// the frame's strongest spectral component, so a mel band far below that PEAK carries a large relative error, which log, DCT
+// and lifter turn into a cepstral error.  Measured against the float64 reference on 1.19 M frames (tools/fe_precision_audit.py):
+// with r = log(largest bin power) - min_j log(mel_j), frames with r <= 10.0 stay within 6.7e-5, r in (10.2, 10.4] reaches
+// 8.9e-5, (10.4, 10.6] 1.1e-4.  (Round 3 first used the span max - min of the log-mel values themselves: it cannot tell white
+// noise, whose peak bin sits well below its strongest band, from a tone, whose peak IS its strongest band, and left four frames
+// of 2.4 M at 1.2-1.5e-4.)  Frames over the threshold are redone in float64 by the refinement kernel (batched) or on the spot
+// (streaming).
+// v: the frame's centred log-mel value in lanes of the frame, 0 (= filter 0's value) in the others; lim: the frame's
+// log(peak) - log(mel_0) - threshold in every lane of the frame.  FULL = false: two frames, one per 32-lane half -- the
+// result is valid in lanes 31 and 63; FULL = true: one frame over 64 lanes, lane 63.  Returns the ballot of (min < lim).
+// Running minimum by DPP row scans; a lane without a source keeps its value (no bound_ctrl); a write and the DPP read of the
+// same register are two wait states apart (VALU -> DPP, hidden from the compiler).
 template <bool FULL>
-__device__ __forceinline__ unsigned long long span_over(float v, float thr) {
-    float mx = v, mn = v;
+__device__ __forceinline__ unsigned long long peak_over(float v, float lim) {
+    float mn = v;
 #define KWS_MM_STEP(ctrl)                                      \
-    "v_max_f32_dpp %0, %0, %0 " ctrl "\n\t"                    \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\t"                    \
+    "s_nop 1\n\t"
+    asm("s_nop 1\n\t"
+        KWS_MM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        KWS_MM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"  // rows 1, 3: lane 15 of the row below joins
+        : "+v"(mn));
+    if constexpr (FULL)
+        asm("s_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"  // rows 2, 3: lane 31 joins
+            : "+v"(mn));
+#undef KWS_MM_STEP
+    return __ballot(mn < lim);
+}
+// the same for two frames held in two registers (more than 32 filters): the two chains alternate
+__device__ __forceinline__ void peak_over2(float va, float vb, float lim_a, float lim_b, bool& over_a, bool& over_b) {
+    float a = va, b = vb;
+#define KWS_MM_STEP(ctrl)                                      \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\t"                    \
     "v_min_f32_dpp %1, %1, %1 " ctrl "\n\t"                    \
     "s_nop 0\n\t"
     asm("s_nop 1\n\t"
@@ -453,20 +516,19 @@ __device__ __forceinline__ unsigned long long span_over(float v, float thr) {
         KWS_MM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
         KWS_MM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf")
         KWS_MM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-        KWS_MM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // rows 1, 3: lane 15 of the row below joins
-        : "+v"(mx), "+v"(mn));
-    if constexpr (FULL)
-        asm("s_nop 1\n\t"
-            KWS_MM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")  // rows 2, 3: lane 31 joins
-            : "+v"(mx), "+v"(mn));
+        KWS_MM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        KWS_MM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b));
 #undef KWS_MM_STEP
-    return __ballot(mx - mn > thr);
+    over_a = (__ballot(a < lim_a) >> 63) & 1ull;
+    over_b = (__ballot(b < lim_b) >> 63) & 1ull;
 }
 
 // One packed frame pair, from the (pre-emphasised, zero-padded) samples in v to the cepstra in global memory:
 // FFT -> split -> power -> sparse mel -> log -> DCT x lifter, c0 = log(frame energy).
 // out_a / out_b: rows of numcep floats for frame a / b (out_b is not touched when has_b is false).
-// Returns the precision flags of the pair (wave-uniform): bit 0 = frame a, bit 1 = frame b spans more than p.refine_span.
+// Returns the precision flags of the pair (wave-uniform): bit 0 = frame a, bit 1 = frame b has a mel band more than p.refine_span
+// (natural-log units of power) below its largest spectral bin.
 __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bool has_b, const FrontendParams& p,
                                           const PairScratch& sc, const cf (&t1)[8], const MelLane& ml, int lane,
                                           float* __restrict__ out_a, float* __restrict__ out_b,
@@ -487,9 +549,9 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
     return 0u;
 #endif
 
-    float ea, eb;
-    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb);
-    wave_sum2(ea, eb);
+    float ea, eb, pka = 0.f, pkb = 0.f;  // frame energies; largest bin power of each frame (the precision flag's reference)
+    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb, &pka, &pkb);
+    wave_sum2_max2(ea, eb, pka, pkb);  // (also with the refinement off: a second copy of the split for that case costs more code than the maxima cost time)
 #if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 2    // stop after the power spectrum
     if (lane < p.numcep) out_a[lane] = ea + eb + pbuf[lane].x;
     return 0u;
@@ -545,7 +607,10 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
             const float cv = j < p.nfilt ? l - (f ? mb : ma) : 0.f;
             lbuf[64 * f + j] = cv;
             if (p.refine_span > 0.f) {  // wave-uniform
-                const unsigned long long over = span_over<false>(cv, p.refine_span);
+                // log(peak) - log(mel_0) - threshold per frame, both frames through one hardware logarithm (v_log_f32: a threshold
+                // needs no more; an all-zero frame: log 0 = -inf, never flagged)
+                const float lim = __logf(f ? pkb : pka) - (f ? mb : ma) - p.refine_span;
+                const unsigned long long over = peak_over<false>(cv, lim);
                 flags = (uint32_t)((over >> 31) & 1u) | ((uint32_t)((over >> 63) & 1u) << 1);
             }
         } else {
@@ -555,9 +620,11 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
             const float cva = lane < p.nfilt ? la - ma : 0.f, cvb = lane < p.nfilt ? lb - mb : 0.f;
             lbuf[lane] = cva;
             lbuf[64 + lane] = cvb;
-            if (p.refine_span > 0.f)
-                flags = (uint32_t)((span_over<true>(cva, p.refine_span) >> 63) & 1u) |
-                        ((uint32_t)((span_over<true>(cvb, p.refine_span) >> 63) & 1u) << 1);
+            if (p.refine_span > 0.f) {
+                bool oa, ob;
+                peak_over2(cva, cvb, __logf(pka) - ma - p.refine_span, __logf(pkb) - mb - p.refine_span, oa, ob);
+                flags = (uint32_t)oa | ((uint32_t)ob << 1);
+            }
         }
     }
     wave_lds_order();

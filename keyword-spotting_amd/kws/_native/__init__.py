@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("KWS_HIP_LIB") or os.path.join(os.path.dirname(os.path
 KWS_OK, KWS_EINVAL, KWS_ENOMEM, KWS_EHIP, KWS_ESTATE, KWS_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 KWS_CT_F16_PAIR, KWS_CT_BF16_TRIPLE = 0, 1  # kws_set_cnn_trad_math
 KWS_K_MFCC, KWS_K_DSCNN, KWS_K_CNNTRAD_CONV, KWS_K_CNNTRAD_DENSE, KWS_K_STREAM_FRAME, KWS_K_MFCC_F64, KWS_K_MFCC_REFINE = 0, 1, 2, 3, 4, 5, 6
-FE_REFINE_SPAN_DEFAULT = 11.5  # KWS_FE_REFINE_SPAN_DEFAULT: log-mel span beyond which a frame is redone in float64
+FE_REFINE_SPAN_DEFAULT = 10.2  # KWS_FE_REFINE_SPAN_DEFAULT: log(largest bin power / weakest mel band) beyond which a frame is redone in float64
 FE_F32, FE_F64 = 0, 1  # KWS_FE_F32 (default: the fast float32 front end) / KWS_FE_F64 (float64 after framing, as psf)
 ACT_FLOATS_PER_CLIP = 64 * (141 + 141 + 245 + 357) + 64 + 64 * 477  # KWS_ACT_FLOATS_PER_CLIP
 PW_F32 = 1          # KWS_PW_F32: pointwise convolutions on v_mfma_f32_32x32x2_f32

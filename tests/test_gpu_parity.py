@@ -63,6 +63,16 @@ def he_model(e2e_golden):
     return model
 
 
+def peak_ratio(clip):
+    """log(largest bin power) - min log(mel energy) per frame, from the oracle's float64 spectrum: the quantity the float32 kernel's
+    precision flag measures (include/kws_hip.h, kws_set_frontend_refine).  An all-zero frame gives -inf (never flagged)."""
+    sig = o_mfcc.fix_length(o_mfcc.pcm16_to_float(clip), 16000)
+    feat, _ = o_mfcc.fbank(sig)
+    ps = o_mfcc.powspec(o_mfcc.framesig(o_mfcc.preemphasis(sig, 0.97), 400, 160), 512)
+    with np.errstate(divide="ignore"):
+        return np.log(ps.max(axis=1)) - np.log(feat).min(axis=1)
+
+
 def gpu_mfcc(ctx, dev, clips):
     wav = torch.from_numpy(np.ascontiguousarray(clips)).to(dev)
     nf, nc = ctx.frontend_shape()
@@ -100,8 +110,9 @@ def test_mfcc_diverse_clips_incl_level_steps(native, ctx, dev, e2e_golden):
     within 1e-4 of the float64 oracle.  The bursts put a loud and a quiet frame into one packed transform (without the
     per-frame level equalisation the quiet frame's cepstra were off by up to 2e-2), and a clean tone over a quiet floor
     spreads its mel bands over 80 dB inside one frame, where a float32 transform (rounding noise ~138 dB below the strongest
-    component) misses by up to 6e-4: such frames are flagged by the float32 kernel (log-mel span > 12) and recomputed in
-    float64 by the refinement launch.  No per-frame allowance is left in this gate."""
+    component) misses by up to 6e-4: such frames are flagged by the float32 kernel (weakest mel band more than 10.2 log units of
+    power below the largest spectral bin) and recomputed in float64 by the refinement launch.  No
+    per-frame allowance is left in this gate."""
     clips, names = e2e_golden["clips"], e2e_golden["names"]
     before = ctx.frontend_stats()
     got = gpu_mfcc(ctx, dev, clips)[:, 0]
@@ -112,7 +123,7 @@ def test_mfcc_diverse_clips_incl_level_steps(native, ctx, dev, e2e_golden):
     assert not over.any(), [(str(names[i]), int(f), float(err[i, f])) for i, f in zip(*np.nonzero(over))][:5]
     # what the refinement did: counted per call, a few percent of these frames, none of them on white noise at full scale
     assert total - before[0] == clips.shape[0] * 99 and refined - before[1] == last
-    assert 0.01 * err.size <= last <= 0.25 * err.size, last
+    assert 0.03 * err.size <= last <= 0.25 * err.size, last
     # ... and nothing else: with the refinement off the other rows keep their bits, and the float32 kernel alone misses
     ctx.set_frontend_refine(0.0)
     try:
@@ -121,10 +132,10 @@ def test_mfcc_diverse_clips_incl_level_steps(native, ctx, dev, e2e_golden):
         ctx.set_frontend_refine(native.FE_REFINE_SPAN_DEFAULT)
     changed = np.any(plain != got, axis=2)
     assert changed.sum() <= last
-    feat = np.stack([o_mfcc.fbank(o_mfcc.fix_length(o_mfcc.pcm16_to_float(c), 16000))[0] for c in clips])
-    span = np.log(feat).max(axis=2) - np.log(feat).min(axis=2)
-    assert not changed[span < native.FE_REFINE_SPAN_DEFAULT - 0.01].any()      # below the threshold: bit-identical to the float32 kernel
-    assert changed[span > native.FE_REFINE_SPAN_DEFAULT + 0.01].mean() > 0.98  # above it: recomputed (a float64 row may round to the same floats)
+    ratio = np.stack([peak_ratio(c) for c in clips])
+    assert last == pytest.approx((ratio > native.FE_REFINE_SPAN_DEFAULT).sum(), abs=4)  # the flag is the quantity the header names
+    assert not changed[ratio < native.FE_REFINE_SPAN_DEFAULT - 0.01].any()      # below the threshold: bit-identical to the float32 kernel
+    assert changed[ratio > native.FE_REFINE_SPAN_DEFAULT + 0.01].mean() > 0.98  # above it: recomputed (a float64 row may round to the same floats)
     assert np.abs(plain - want).max() > 2 * TOL                                # the float32 kernel alone does not meet the gate here
     # a frame's result must not depend on its partner in the packed pair: frame 2k of a clip whose odd frames are loud
     loud = synth_clips(1, 12)[0].astype(np.int32)
@@ -137,49 +148,32 @@ def test_mfcc_diverse_clips_incl_level_steps(native, ctx, dev, e2e_golden):
     assert np.abs(got2 - want2).max() <= TOL
 
 
-def test_mfcc_audit_hard_clips_need_the_11p5_threshold(native, ctx, dev):
-    """The four clips of the 1.19 M-frame audit (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt) in which a frame
-    with a log-mel span between 11.5 and 12.0 missed 1e-4 under round 2's threshold of 12.0: every frame is within the
-    tolerance at the shipped threshold, and the named frames miss it again when the threshold is put back -- the fixture
-    pins the reason the default is 11.5."""
-    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_hard_clips.npz"))
-    clips, frames = d["clips"], d["frames"]
+def test_mfcc_audit_clips_every_frame_within_tol(native, ctx, dev):
+    """Eight clips of the 3.56 M-frame audit (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt) on which round 3's
+    FIRST flag -- the span max - min of a frame's log-mel values -- failed: four with a frame that missed 1e-4 at a span threshold
+    of 12.0, four more that missed it (1.2e-4 .. 1.5e-4) at 11.5.  The flag the kernel has now measures the weakest band against
+    the frame's largest spectral BIN (what the float32 transform's noise is relative to): every frame of the eight is within
+    the tolerance, every named frame is over the threshold by a margin, and with the refinement off they miss again."""
+    named, clips = [], []
+    for name in ("audit_hard_clips.npz", "audit_exception_clips.npz"):
+        d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+        for c, fr in zip(d["clips"], d["frames"]):
+            named += [(len(clips), int(f)) for f in np.atleast_1d(fr) if f >= 0]
+            clips.append(c)
+    clips = np.stack(clips)
     want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
-    assert native.FE_REFINE_SPAN_DEFAULT <= 11.5
     got = gpu_mfcc(ctx, dev, clips)[:, 0]
     err = np.abs(got - want).max(axis=2)
     assert err.max() <= TOL, (float(err.max()), np.unravel_index(err.argmax(), err.shape))
-    ctx.set_frontend_refine(12.0)
+    ratio = np.stack([peak_ratio(c) for c in clips])
+    assert all(ratio[i, f] > native.FE_REFINE_SPAN_DEFAULT + 0.5 for i, f in named), [float(ratio[i, f]) for i, f in named]
+    ctx.set_frontend_refine(0.0)
     try:
-        old = gpu_mfcc(ctx, dev, clips)[:, 0]
+        raw = gpu_mfcc(ctx, dev, clips)[:, 0]
     finally:
         ctx.set_frontend_refine(native.FE_REFINE_SPAN_DEFAULT)
-    err_old = np.abs(old - want).max(axis=2)
-    named = [(i, int(f)) for i, fr in enumerate(frames) for f in fr if f >= 0]
-    assert all(err_old[i, f] > TOL for i, f in named), [(i, f, float(err_old[i, f])) for i, f in named]
-    assert (err_old > TOL).sum() == len(named)
-
-
-def test_mfcc_documented_exceptions_stay_small_and_float64_has_none(native, dev):
-    """The four frames (of 2.38 M audited after the threshold had been set; profiles/r03_precision_audit.txt) on which the default
-    front end misses 1e-4: tone / chirp mixtures, log-mel spans 10.8-11.5 (under the refinement threshold), float32 errors
-    1.2e-4 .. 1.5e-4.  include/kws_hip.h names them as the exceptions of KWS_FE_F32's contract; this test pins their size, that
-    they are confined to the named frames, and that KWS_FE_F64 -- the strict setting -- meets the bound on all of them."""
-    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_exception_clips.npz"))
-    clips, frames = d["clips"], d["frames"]
-    want = np.stack([o_mfcc.extract_features_pcm16(c) for c in clips])
-    c = native.Context(0)
-    try:
-        got = gpu_mfcc(c, dev, clips)[:, 0]
-        err = np.abs(got - want).max(axis=2)
-        assert err.max() <= 2 * TOL, float(err.max())
-        over = np.argwhere(err > TOL)
-        assert {(int(i), int(f)) for i, f in over} <= {(i, int(f)) for i, f in enumerate(frames)}, over
-        c.set_frontend_math(native.FE_F64)
-        strict = gpu_mfcc(c, dev, clips)[:, 0]
-        assert np.abs(strict - want).max() <= TOL
-    finally:
-        c.close()
+    err_raw = np.abs(raw - want).max(axis=2)
+    assert all(err_raw[i, f] > TOL for i, f in named), [(i, f, float(err_raw[i, f])) for i, f in named]
 
 
 @pytest.mark.parametrize("kind,seed", [("uniform", 0), ("gauss", 1)])

@@ -271,13 +271,23 @@ def test_endpointer_known_answer():
     assert not any(short.update(0.0 if 10 <= t < 40 else -36.0)[0] for t in range(200))  # 30 voiced hops never reach 80 % of 40
 
 
-def test_audit_fixture_frames_sit_between_the_old_and_the_new_refinement_threshold():
-    """tests/golden/audit_hard_clips.npz (make_audit_fixture.py): the named frames have a log-mel span in (11.5, 12.0] --
-    flagged for the float64 refinement at the shipped threshold, not at round 2's."""
-    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "audit_hard_clips.npz"))
-    assert d["clips"].shape == (4, 16000) and d["clips"].dtype == np.int16
-    for c, fr in zip(d["clips"], d["frames"]):
-        feat, _ = o.fbank(o.fix_length(o.pcm16_to_float(c), 16000))
-        lm = np.log(feat)
-        span = lm.max(1) - lm.min(1)
-        assert all(11.5 < span[f] <= 12.0 for f in fr if f >= 0), span[fr]
+def test_audit_fixtures_hold_what_their_names_say():
+    """tests/golden/audit_hard_clips.npz and audit_exception_clips.npz (make_audit_fixture.py): the named frames have log-mel
+    spans of 11.5-12.0 and 10.8-11.5 -- under the span thresholds round 3 tried first -- and lie well over the threshold of the
+    flag the kernel has now (largest spectral bin against the weakest mel band, default 10.2)."""
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    for name, lo, hi in (("audit_hard_clips.npz", 11.5, 12.0), ("audit_exception_clips.npz", 10.8, 11.5)):
+        d = np.load(os.path.join(here, name))
+        assert d["clips"].shape == (4, 16000) and d["clips"].dtype == np.int16
+        for c, fr in zip(d["clips"], d["frames"]):
+            sig = o.fix_length(o.pcm16_to_float(c), 16000)
+            feat, _ = o.fbank(sig)
+            lm = np.log(feat)
+            span = lm.max(1) - lm.min(1)
+            ps = o.powspec(o.framesig(o.preemphasis(sig, 0.97), 400, 160), 512)
+            with np.errstate(divide="ignore"):
+                ratio = np.log(ps.max(1)) - lm.min(1)
+            for f in np.atleast_1d(fr):
+                if f >= 0:
+                    assert lo < span[f] <= hi, (name, f, span[f])
+                    assert ratio[f] > 10.7, (name, f, ratio[f])

@@ -23,10 +23,10 @@ dev = torch.device("cuda", 0)
 ctx = _native.Context(0)
 if thr is not None:
     ctx.set_frontend_refine(thr)
-print(f"front-end precision audit: {N} clips per generator, seed {seed}, refinement span threshold {_native.FE_REFINE_SPAN_DEFAULT if thr is None else thr}")
+print(f"front-end precision audit: {N} clips per generator, seed {seed}, refinement threshold {_native.FE_REFINE_SPAN_DEFAULT if thr is None else thr}")
 worst_all, over_all, frames_all = 0.0, 0, 0
-span_bins = [(0, 8), (8, 9), (9, 9.5), (9.5, 10), (10, 10.25), (10.25, 10.5), (10.5, 10.75), (10.75, 11), (11, 11.25), (11.25, 11.5), (11.5, 11.75),
-             (11.75, 12.0), (12.0, 12.5), (12.5, 13), (13, 14), (14, 99)]
+span_bins = [(-1e9, 7), (7, 8), (8, 8.5), (8.5, 9), (9, 9.5), (9.5, 9.8), (9.8, 10.0), (10.0, 10.2), (10.2, 10.4), (10.4, 10.6), (10.6, 11.0), (11.0, 11.5),
+             (11.5, 12.0), (12.0, 13), (13, 14), (14, 1e9)]
 by_span = {b: [0, 0.0] for b in span_bins}
 dump = []   # per frame: raw error, log-mel span, log of sum_j exp(2 (Lmax - L_j)), the largest |error| cepstrum index, generator id
 dump_path = os.environ.get("KWS_AUDIT_DUMP")
@@ -42,9 +42,12 @@ for tag, clips in sets.items():
     for ci, c in enumerate(clips):
         want = o.extract_features_pcm16(c)
         err = np.abs(got[ci] - want).max(axis=1)
-        feat, _ = o.fbank(o.fix_length(o.pcm16_to_float(c), 16000))
+        sig = o.fix_length(o.pcm16_to_float(c), 16000)
+        feat, _ = o.fbank(sig)
         lm = np.log(feat)
-        span = lm.max(1) - lm.min(1)
+        ps = o.powspec(o.framesig(o.preemphasis(sig, 0.97), 400, 160), 512)
+        with np.errstate(divide="ignore"):
+            span = np.log(ps.max(1)) - lm.min(1)   # the flag's quantity: largest bin against the weakest mel band (round 3's first flag: lm.max(1) - lm.min(1))
         if dump_path:
             lse = np.log(np.exp(2.0 * (lm.max(1, keepdims=True) - lm)).sum(1))
             dump.append(np.stack([err, span, lse, np.abs(got[ci] - want).argmax(axis=1), np.full(99, list(sets).index(tag))], 1).astype(np.float32))
@@ -59,9 +62,9 @@ for tag, clips in sets.items():
     print(f"  {tag:10s} {n:7d} frames: worst |err| {worst:.2e}, over 1e-4: {over}, refined in float64: {after[1] - before[1]} ({100.0 * (after[1] - before[1]) / n:.2f} %)")
     worst_all, over_all, frames_all = max(worst_all, worst), over_all + over, frames_all + n
 print(f"ALL: {frames_all} frames, worst |err| {worst_all:.2e}, frames over 1e-4: {over_all}")
-print("worst error by log-mel span of the frame (frames above the threshold were refined in float64):")
+print("worst error by r = log(largest bin power) - min log(mel) of the frame (frames above the threshold were refined in float64):")
 for b in span_bins:
-    print(f"  span ({b[0]:4.1f}, {b[1]:4.1f}]: {by_span[b][0]:7d} frames, worst |err| {by_span[b][1]:.2e}")
+    print(f"  r ({max(b[0], 0):4.1f}, {min(b[1], 99):4.1f}]: {by_span[b][0]:7d} frames, worst |err| {by_span[b][1]:.2e}")
 ctx.close()
 if dump_path:
     np.save(dump_path, np.concatenate(dump))
