@@ -267,6 +267,25 @@ __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KW
     const PairScratch sc = {reinterpret_cast<cf*>(scr + SCR_XBUF), reinterpret_cast<float2*>(scr + SCR_PBUF),
                             reinterpret_cast<float*>(scr + SCR_LBUF), dctb, tw2, nfp};
     const float pre = p.preemph;
+    // The wavefront's flagged pairs go to the worklist together: two flag bits per pair collect in one scalar mask (pair k of the
+    // wavefront at bits 2k, 2k+1; a register per entry would spill under the 128-register cap), and when the wavefront is done --
+    // or 16 pairs are in -- lane k rebuilds pair k's entry from the mask, ONE 64-bit atomic reserves the slots (entries in the low
+    // word: its old value is the first slot; flagged frames in the high word) and the lanes store side by side.  An atomic per
+    // flagged pair queued up at the counter's L2 line when flags are dense (speech-like clips, 5 % of the frames: 0.194 -> 0.262 ms).
+    uint32_t fmask = 0u;
+    int pair0 = 2 * c;  // pair index (within the clip) of mask position 0
+#define KWS_FLUSH_FLAGS()                                                                                                          \
+    if (fmask && rl.ctr) {                                                                                                          \
+        const uint32_t fk = lane < 16 ? (fmask >> (2 * lane)) & 3u : 0u;                                                            \
+        const uint32_t has = (uint32_t)__ballot(fk != 0u);                                                                          \
+        unsigned long long old = 0ull;                                                                                              \
+        if (lane == 0)                                                                                                              \
+            old = atomicAdd(reinterpret_cast<unsigned long long*>(rl.ctr),                                                          \
+                            (unsigned long long)__builtin_popcount(has) | ((unsigned long long)__builtin_popcount(fmask) << 32));   \
+        const int at = __builtin_amdgcn_readfirstlane((int)(unsigned)old) + __builtin_popcount(has & ((1u << (lane & 31)) - 1u));   \
+        if (fk != 0u && at < rl.cap)                                                                                                \
+            rl.list[at] = (int)((((unsigned)(rl.clip0 + clip) * (unsigned)((p.num_frames + 1) / 2) + (unsigned)(pair0 + lane)) << 2) | fk); \
+    }
     for (; c < c_end; ++c) {
 #ifndef KWS_X_MFCC_PREFETCH
         fetch(c);
@@ -337,14 +356,17 @@ __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KW
             const uint32_t flags = mfcc_pair(v, nza, nzb, has_b, p, sc, t1, ml, lane,
                                              out + ((size_t)clip * p.num_frames + fa) * p.numcep,
                                              out + ((size_t)clip * p.num_frames + fa + 1) * p.numcep);
-            if (flags && rl.ctr && lane == 0) {  // (see the tile kernel)
-                const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(rl.ctr), 1ull | ((unsigned long long)__builtin_popcount(flags) << 32));
-                const int at = (int)(unsigned)old;
-                if (at < rl.cap) rl.list[at] = (int)((((unsigned)(rl.clip0 + clip) * (unsigned)((p.num_frames + 1) / 2) + (unsigned)(fa >> 1)) << 2) | flags);
-            }
+            fmask |= flags << (2 * ((fa >> 1) - pair0));  // wave-uniform
             wave_lds_order();
         }
+        if (2 * (c + 1) - pair0 >= 16) {  // the mask is full (more than 8 chunks per wavefront: tuning runs only)
+            KWS_FLUSH_FLAGS()
+            fmask = 0u;
+            pair0 = 2 * (c + 1);
+        }
     }
+    KWS_FLUSH_FLAGS()
+#undef KWS_FLUSH_FLAGS
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -326,6 +326,13 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
             pb[j] = nzb ? pb[j] : 0.f;
         }
     }
+    if (pk_a) {  // this lane's largest bin power per frame: the precision flag measures the weakest mel band against the frame's peak
+        // (v_max3_f32 in asm: fmaxf costs a canonicalising v_max per operand on top of the maximum itself)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(*pk_a) : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(*pk_b) : "v"(pb[0]), "v"(pb[1]), "v"(pb[2]));
+        asm("v_max_f32 %0, %0, %1" : "+v"(*pk_a) : "v"(pa[3]));
+        asm("v_max_f32 %0, %0, %1" : "+v"(*pk_b) : "v"(pb[3]));
+    }
     ea = 0.f;
     eb = 0.f;
 #pragma unroll
@@ -346,23 +353,10 @@ __device__ __forceinline__ void split_power(const cf (&v)[8], cf* zbuf, float2* 
         if (slot256 >= 0) pbuf[slot256] = make_float2(pa, pb);
         ea += pa;
         eb += pb;
-        if (pk_a) {  // (bin 256 joins this lane's peak below)
-            *pk_a = pa;
-            *pk_b = pb;
+        if (pk_a) {  // bin 256 joins this lane's peaks
+            asm("v_max_f32 %0, %0, %1" : "+v"(*pk_a) : "v"(pa));
+            asm("v_max_f32 %0, %0, %1" : "+v"(*pk_b) : "v"(pb));
         }
-    } else if (pk_a) {
-        *pk_a = 0.f;
-        *pk_b = 0.f;
-    }
-    if (pk_a) {  // this lane's largest bin power per frame: the precision flag measures the weakest mel band against the frame's peak
-        // (two v_max3_f32 per frame; fmaxf costs a canonicalising v_max per operand on top of the maximum itself)
-        float ta, tb, ka = *pk_a, kb = *pk_b;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ta) : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tb) : "v"(pb[0]), "v"(pb[1]), "v"(pb[2]));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(ka) : "v"(ta), "v"(pa[3]), "v"(ka));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(kb) : "v"(tb), "v"(pb[3]), "v"(kb));
-        *pk_a = ka;
-        *pk_b = kb;
     }
     wave_lds_order();
 }
@@ -550,8 +544,13 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
 #endif
 
     float ea, eb, pka = 0.f, pkb = 0.f;  // frame energies; largest bin power of each frame (the precision flag's reference)
-    split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb, &pka, &pkb);
-    wave_sum2_max2(ea, eb, pka, pkb);  // (also with the refinement off: a second copy of the split for that case costs more code than the maxima cost time)
+    if (p.refine_span > 0.f) {  // wave-uniform
+        split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb, &pka, &pkb);
+        wave_sum2_max2(ea, eb, pka, pkb);
+    } else {
+        split_power(v, xbuf, pbuf, lane, 1, nza, nzb, ml.pslot, -1, lv, ea, eb);
+        wave_sum2(ea, eb);
+    }
 #if defined(KWS_X_MFCC_STOP) && KWS_X_MFCC_STOP == 2    // stop after the power spectrum
     if (lane < p.numcep) out_a[lane] = ea + eb + pbuf[lane].x;
     return 0u;
