@@ -276,6 +276,7 @@ __global__ __launch_bounds__(MFCC_THREADS) __attribute__((amdgpu_waves_per_eu(KW
     int pair0 = 2 * c;  // pair index (within the clip) of mask position 0
 #define KWS_FLUSH_FLAGS()                                                                                                          \
     if (fmask && rl.ctr) {                                                                                                          \
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); /* (recomputed: the loop's copy would have to be kept in scratch) */ \
         const uint32_t fk = lane < 16 ? (fmask >> (2 * lane)) & 3u : 0u;                                                            \
         const uint32_t has = (uint32_t)__ballot(fk != 0u);                                                                          \
         unsigned long long old = 0ull;                                                                                              \
