@@ -100,9 +100,9 @@ int kws_frontend_math(kws_ctx* ctx);
  * lies below its largest spectral bin: r = log(max bin power) - min log(mel energy) (natural-log units of power).  A frame
  * with r over `log_ratio` (default 10.2 = 44 dB) goes onto a device worklist and a second launch recomputes exactly those
  * rows in float64 (no host read-back; a batch with nothing listed pays one empty launch).  Frames under the threshold keep
- * the float32 kernel's bits.  Measured against the float64 oracle on 3.56 M frames of noise, tones, chirps, gated bursts,
- * mixtures and speech-like clips (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt): unflagged frames with
- * r <= 10.2 stay within 7.3e-5 (one burst-onset frame in 3.56 M at 9.4e-5).  White noise lists ~0.3 % of its frames,
+ * the float32 kernel's bits.  Measured against the float64 oracle on 10.7 M frames of noise, tones, chirps, gated bursts,
+ * mixtures and speech-like clips (tools/fe_precision_audit.py, profiles/r03_precision_audit.txt): no frame over 1e-4, the
+ * worst of a seed's 297 000 frames 6.6e-5 .. 8.4e-5 (two seeds of 36: 9.3e-5 and 9.4e-5).  White noise lists ~0.3 % of its frames,
  * speech-like clips ~5 %, a clean tone over a quiet floor all of them.  (Until late in round 3 the flag was the span max - min
  * of the log-mel values with a threshold of 11.5: it cannot tell white noise, whose peak bin lies well below its strongest
  * band, from a tone, and left four frames of 2.4 M at 1.2-1.5e-4.)  The streaming push redoes a flagged frame in float64
