@@ -134,13 +134,15 @@ __global__ __launch_bounds__(REFINE_WAVES * 64) void kws_mfcc_refine_kernel(Fron
     const int n_waves = blockDim.x >> 6;
     const int raw = *const_cast<volatile int*>(rl.ctr);
     const int n = raw < rl.cap ? raw : rl.cap;
-    if ((int)blockIdx.x * n_waves < n) {  // workgroup-uniform
+    // Entry e goes to workgroup e mod grid, wavefront e / grid: a short list (white noise: ~1 000 pairs for 3 072 wavefronts) is spread
+    // one wavefront per SIMD over all CUs instead of filling a third of them three deep.
+    if ((int)blockIdx.x < n) {  // workgroup-uniform
         const int n_used = p.frame_len < NCT ? p.frame_len : NCT;
         const int pairs_per_clip = (p.num_frames + 1) / 2;
         const F64Layout lay = f64_layout(NCT, true, true, p.nfilt, p.numcep, n_waves);
         d2* const X = reinterpret_cast<d2*>(smem64 + lay.wave0 + wv * lay.per_wave);
         // this wavefront's first pair goes to its private buffer while the workgroup's tables are still on their way
-        int e = blockIdx.x * n_waves + wv;
+        int e = wv * gridDim.x + blockIdx.x;
         int entry = 0, clip = 0, fa = 0;
         bool has_b = false, nza = false, nzb = false;
         auto fetch = [&]() {
@@ -181,9 +183,7 @@ __global__ __launch_bounds__(REFINE_WAVES * 64) void kws_mfcc_refine_kernel(Fron
     // workgroup 0 alone when the list is empty.  A workgroup without work does not touch the counter -- with every workgroup
     // adding to one address across eight XCDs the empty launch took 15.6 us, most of it that queue of atomics.  A would-be
     // participant that has not started yet has not added either, so the reset cannot overtake its read of n.
-    const int per_wg = n_waves;
-    int participants = (n + per_wg - 1) / per_wg;
-    participants = participants < 1 ? 1 : (participants > (int)gridDim.x ? (int)gridDim.x : participants);
+    int participants = n < 1 ? 1 : (n > (int)gridDim.x ? (int)gridDim.x : n);
     if ((int)blockIdx.x >= participants) return;
     if (tid == 0 && atomicAdd(&rl.ctr[6], 1) == participants - 1) {
         const int rows = rl.ctr[1];  // flagged frames, counted by the float32 kernel next to its list entries
