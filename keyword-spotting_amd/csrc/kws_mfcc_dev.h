@@ -608,7 +608,7 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
             if (p.refine_span > 0.f) {  // wave-uniform
                 // log(peak) - log(mel_0) - threshold per frame, both frames through one hardware logarithm (v_log_f32: a threshold
                 // needs no more; an all-zero frame: log 0 = -inf, never flagged)
-                const float lim = __logf(f ? pkb : pka) - (f ? mb : ma) - p.refine_span;
+                const float lim = 0.6931471806f * __builtin_amdgcn_logf(f ? pkb : pka) - (f ? mb : ma) - p.refine_span;  // (v_log_f32, bare: a peak power is no subnormal)
                 const unsigned long long over = peak_over<false>(cv, lim);
                 flags = (uint32_t)((over >> 31) & 1u) | ((uint32_t)((over >> 63) & 1u) << 1);
             }
@@ -621,7 +621,7 @@ __device__ __forceinline__ uint32_t mfcc_pair(cf (&v)[8], bool nza, bool nzb, bo
             lbuf[64 + lane] = cvb;
             if (p.refine_span > 0.f) {
                 bool oa, ob;
-                peak_over2(cva, cvb, __logf(pka) - ma - p.refine_span, __logf(pkb) - mb - p.refine_span, oa, ob);
+                peak_over2(cva, cvb, 0.6931471806f * __builtin_amdgcn_logf(pka) - ma - p.refine_span, 0.6931471806f * __builtin_amdgcn_logf(pkb) - mb - p.refine_span, oa, ob);
                 flags = (uint32_t)oa | ((uint32_t)ob << 1);
             }
         }
